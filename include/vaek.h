@@ -1,0 +1,173 @@
+/*
+ * vaek.h -- C ABI of the MI355X-native ELBO train-step library (libvaek.so).
+ *
+ * The reference (virajmehta/vae-training) is pure Python on JAX/Flax and has no FFI; the
+ * "native kernels" it runs are the XLA programs behind the calls cited on each entry point
+ * below (paths relative to /root/reference).  This header is therefore the boundary a
+ * maintainer would bind from Python with ctypes to replace
+ *     VAE.train_step   networks.py:87-101   (forward + ELBO + backward + Adam, one jitted fn)
+ *     VAE.loss         networks.py:103-113  (forward + ELBO, eval twin)
+ *     VAE.apply        networks.py:61-84    (model(batch, z1, z2[, sampling=True]))
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative vaek_status otherwise; it never throws
+ *     and never aborts.  vaek_last_error() returns a thread-local message for the last failure.
+ *   - every device buffer is owned by the caller (PyTorch-ROCm tensors on the Python side);
+ *     the library receives raw device pointers and a hipStream_t (passed as void*), launches
+ *     asynchronously on that stream and never synchronises or allocates after ctx_create
+ *     (vaek_comm_* excepted: it maps peer memory once at init).
+ *   - matrices are row-major; Dense kernels are [in, out] exactly as flax.nn.Dense stores
+ *     them; all floating-point buffers are float32 unless a name says bf16.
+ *   - parameters, gradients and both Adam moments each live in ONE flat float32 buffer with
+ *     the fixed leaf order
+ *         Encoder/FC0/kernel, Encoder/FC0/bias, ..., Decoder/FC0/kernel, ...,
+ *         [SigDecoder/FC0/kernel, ...,]  epsilon_p (L),  [epsilon (1)]
+ *     (names as in networks.py:67-78 and vae.py:73-80).  The gradient buffer has
+ *     vaek_grad_len() = P + 4 floats: [P] = loss, [P+1] = mean Dkl, [P+2] = mean mse, [P+3] = 0,
+ *     so that a data-parallel sum of the buffer also yields the global loss.
+ *   - one host thread per context; one process per GPU for data parallelism.
+ */
+#ifndef VAEK_H
+#define VAEK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VAEK_VERSION 100 /* 0.1.0 */
+#define VAEK_MAX_HIDDEN 8
+
+typedef enum vaek_status {
+    VAEK_OK = 0,
+    VAEK_ERR_INVALID = -1,   /* bad argument / unsupported configuration */
+    VAEK_ERR_HIP = -2,       /* a HIP runtime call failed                 */
+    VAEK_ERR_NO_DEVICE = -3, /* no usable gfx950 device                   */
+    VAEK_ERR_WORKSPACE = -4, /* workspace too small / misaligned          */
+    VAEK_ERR_COMM = -5       /* peer-to-peer communicator failure         */
+} vaek_status;
+
+/* Activation codes of vaek_dense_fwd / vaek_dense_bwd_dx. */
+enum { VAEK_ACT_NONE = 0, VAEK_ACT_RELU = 1 };
+
+/* Compute dtype of the Dense GEMMs (ELBO, reductions and Adam are always float32). */
+enum { VAEK_F32 = 0, VAEK_BF16 = 1 };
+
+/* What VAE.partial binds at vae.py:57-59 plus the batch geometry. */
+typedef struct vaek_config {
+    int32_t struct_size;                  /* = sizeof(vaek_config), ABI guard                      */
+    int32_t batch;                        /* rows handed to this rank per step (B_local)           */
+    int32_t data_dim;                     /* D = prod(dataset.shape), vae.py:51                    */
+    int32_t latent_dim;                   /* L, vae.py:50                                          */
+    int32_t n_enc_hidden;                 /* encoder_layer_sizes without the appended L, vae.py:53 */
+    int32_t enc_hidden[VAEK_MAX_HIDDEN];
+    int32_t n_dec_hidden;                 /* layer_sizes without the appended D, vae.py:54         */
+    int32_t dec_hidden[VAEK_MAX_HIDDEN];
+    int32_t sigmoid_decoder;              /* dataset_name == "sigmoid": SigDecoder + Decoder, networks.py:75-78 */
+    int32_t tunable_eps;                  /* -tdv: epsilon is a (1,) parameter times eps_cli, networks.py:70-71 */
+    float   eps_cli;                      /* -e/--epsilon, run.py:31                               */
+    int32_t dtype;                        /* VAEK_F32 | VAEK_BF16                                  */
+    int32_t device;                       /* HIP device ordinal                                    */
+    int32_t world;                        /* data-parallel ranks (1 = single GPU)                  */
+    int32_t rank;
+    int64_t global_batch;                 /* divisor of loss.mean() (networks.py:98); 0 -> batch*world */
+    int32_t force_generic;                /* 1: never pick the fused small-model kernels (tests)   */
+    int32_t reserved[7];
+} vaek_config;
+
+typedef struct vaek_ctx vaek_ctx;
+
+/* ---- library ---------------------------------------------------------------------------- */
+int vaek_version(void);
+const char* vaek_last_error(void);
+
+/* ---- context: replaces VAE.partial(...) + init_by_shape shape inference, vae.py:57-60 ---- */
+int vaek_ctx_create(const vaek_config* cfg, vaek_ctx** out);
+int vaek_ctx_destroy(vaek_ctx* ctx);
+/* P = number of trainable floats; grad_len = P + 4 (see conventions). */
+int vaek_param_count(const vaek_ctx* ctx, int64_t* P);
+int vaek_grad_len(const vaek_ctx* ctx, int64_t* n);
+/* Leaf table of the flat layout: n_leaves, then per leaf its offset and (rows, cols);
+ * a bias / epsilon_p / epsilon leaf has rows == 1.  name buffers are NUL-terminated. */
+int vaek_leaf_count(const vaek_ctx* ctx, int32_t* n_leaves);
+int vaek_leaf_info(const vaek_ctx* ctx, int32_t leaf, char* name, int32_t name_cap,
+                   int64_t* offset, int32_t* rows, int32_t* cols);
+/* Bytes of caller-owned scratch (256-byte aligned) every entry point taking `workspace` needs. */
+int vaek_workspace_bytes(const vaek_ctx* ctx, size_t* bytes);
+/* 1 if the fused small-model path is used for train_step/loss_eval, 0 for layer-by-layer. */
+int vaek_uses_fused_path(const vaek_ctx* ctx, int32_t* fused);
+
+/* ---- building blocks (also used by the layer-by-layer path of vaek_train_step) ----------- */
+/* flax.nn.Dense + relu, networks.py:34-39: y[rows,n_out] = act(x[rows,n_in] @ w[n_in,n_out] + b). */
+int vaek_dense_fwd(vaek_ctx* ctx, const float* x, const float* w, const float* b, float* y,
+                   int32_t rows, int32_t n_in, int32_t n_out, int32_t act, void* stream);
+/* dx[rows,n_in] = (dy[rows,n_out] @ w^T) * (act == RELU ? x_post > 0 : 1); x_post is the
+ * layer's INPUT as produced by the previous layer's relu (may be NULL for ACT_NONE).
+ * accumulate != 0 adds into dx instead of overwriting (the two decoders of networks.py:76-78). */
+int vaek_dense_bwd_dx(vaek_ctx* ctx, const float* dy, const float* w, const float* x_post, float* dx,
+                      int32_t rows, int32_t n_in, int32_t n_out, int32_t act, int32_t accumulate, void* stream);
+/* dwb[(n_in+1), n_out]: rows 0..n_in-1 = x^T @ dy (kernel gradient), row n_in = column sums of
+ * dy (bias gradient) -- i.e. exactly the [kernel | bias] slice of the flat gradient buffer.
+ * Deterministic (split over the batch into workspace slabs, then summed in a fixed order). */
+int vaek_dense_bwd_dw(vaek_ctx* ctx, const float* x, const float* dy, float* dwb,
+                      int32_t rows, int32_t n_in, int32_t n_out, void* workspace, void* stream);
+/* networks.py:94-98 on explicit tensors.  x_hat_lin = Decoder(samples) WITHOUT the z2 noise;
+ * x_hat_sig = SigDecoder pre-sigmoid output or NULL.  Writes out4 = {loss, mean Dkl, mean mse,
+ * dL/d eps} (means over `batch_total`), and if d_lin != NULL the gradients w.r.t. the two
+ * decoder outputs (d_sig may alias x_hat_sig, d_lin may alias x_hat_lin). */
+int vaek_elbo_fwd_bwd(vaek_ctx* ctx, const float* x, const float* x_hat_lin, const float* x_hat_sig,
+                      const float* z2, const float* mu, const float* logvar_e, float eps,
+                      float* d_lin, float* d_sig, float* out4, int32_t rows, int32_t data_dim,
+                      int32_t latent_dim, int64_t batch_total, void* workspace, void* stream);
+/* flax.optim.Adam.apply_gradient, networks.py:100 (beta1 .9, beta2 .999, eps 1e-8).
+ * `step_dev` (device int32, may be NULL) holds t of THIS update (1-based) when non-NULL,
+ * otherwise `step` is used.  grad_scale multiplies the gradient first (1/world for means). */
+int vaek_adam_step(vaek_ctx* ctx, float* params, const float* grads, float* m, float* v, int64_t n,
+                   float lr, int32_t step, const int32_t* step_dev, float grad_scale, void* stream);
+
+/* ---- the hot path ------------------------------------------------------------------------ */
+/* VAE.train_step, networks.py:87-101, in place: reads params, x[B,D], z1[B,L], z2[B,D];
+ * writes grads (vaek_grad_len floats; summed over ranks when the communicator is initialised),
+ * updates params/m/v, increments *step_dev (device int32 Adam step counter), leaves the loss
+ * in grads[P] (device; the reference keeps it un-synced too, vae.py:130). */
+int vaek_train_step(vaek_ctx* ctx, float* params, float* grads, float* m, float* v, int32_t* step_dev,
+                    const float* x, const float* z1, const float* z2, float lr,
+                    void* workspace, void* stream);
+/* The two halves of vaek_train_step, for callers that all-reduce grads themselves (RCCL via
+ * torch.distributed): grads_only leaves the LOCAL gradient sums (already divided by
+ * global_batch) in grads and does not touch params; apply runs Adam on grads. */
+int vaek_train_step_grads_only(vaek_ctx* ctx, const float* params, float* grads, int32_t* step_dev,
+                               const float* x, const float* z1, const float* z2,
+                               void* workspace, void* stream);
+int vaek_train_step_apply(vaek_ctx* ctx, float* params, const float* grads, float* m, float* v,
+                          const int32_t* step_dev, float lr, void* stream);
+/* VAE.loss, networks.py:103-113: out4 = {loss, mean Dkl, mean mse, eps}. */
+int vaek_loss_eval(vaek_ctx* ctx, const float* params, const float* x, const float* z1, const float* z2,
+                   float* out4, void* workspace, void* stream);
+/* VAE.apply, networks.py:61-84.  sampling != 0: mu = 0, logvar_e = 0, samples = z1 and `eps`
+ * is used as given (vae.py:199); otherwise x is encoded and eps comes from the parameters
+ * (`eps` ignored).  x_hat[rows,D] includes the z2 noise; mu_out[rows,L] may be NULL. */
+int vaek_forward(vaek_ctx* ctx, const float* params, const float* x, const float* z1, const float* z2,
+                 int32_t sampling, float eps, float* x_hat, float* mu_out, int32_t rows,
+                 void* workspace, void* stream);
+
+/* ---- data-parallel exchange over xGMI (one-shot peer-to-peer all-reduce of the flat grads) -- */
+/* Every rank allocates nothing itself: it passes a caller-owned device buffer `comm_buf` of
+ * vaek_comm_buffer_bytes() bytes (hipMalloc'ed, zero-filled), exports it with
+ * vaek_comm_export, exchanges the 64-byte handles out of band (torch.distributed all_gather)
+ * and opens all of them with vaek_comm_init.  After that vaek_train_step sums gradients over
+ * ranks inside its finalize kernel.  Without a communicator and world > 1, use
+ * vaek_train_step_grads_only + an RCCL all-reduce + vaek_train_step_apply. */
+int vaek_comm_buffer_bytes(const vaek_ctx* ctx, size_t* bytes);
+int vaek_comm_export(vaek_ctx* ctx, void* comm_buf, uint8_t handle_out[64]);
+int vaek_comm_init(vaek_ctx* ctx, void* comm_buf, const uint8_t* all_handles /* world x 64 */);
+int vaek_comm_destroy(vaek_ctx* ctx);
+/* Stand-alone sum all-reduce of n floats in place through the communicator (n <= grad_len). */
+int vaek_comm_allreduce(vaek_ctx* ctx, float* buf, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAEK_H */

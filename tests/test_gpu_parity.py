@@ -1,0 +1,144 @@
+"""-m gpu parity tests: the HIP path, called through the C ABI (include/vaek.h), against the
+float64 oracle and the committed golden fixtures.  Tolerances (float32 arithmetic vs float64):
+  loss      1e-5 relative        (BASELINE.json north_star: "within 1e-5 relative ELBO")
+  gradient  2e-5 of the leaf-set max-abs
+  params after k Adam steps: 2% of one Adam step (lr) absolute -- Adam's first updates are
+            -lr*g/(|g|+1e-8), so a float32 ulp on a ~1e-8 gradient moves the update visibly.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import elbo_oracle as O
+from tests.cases import CASES, build
+from tests.gpu_util import check_layout, dev, engine_for, host, load_golden, random_problem, rel_err
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-5
+GRAD_RTOL = 2e-5
+
+
+@pytest.mark.parametrize("force_generic", [True, False])
+@pytest.mark.parametrize("name", list(CASES))
+def test_golden_train_steps(name, force_generic):
+    cfg, dk, B, lr = build(name)
+    f, meta = load_golden(name)
+    eng = engine_for(cfg, B, force_generic=force_generic)
+    check_layout(eng, cfg)
+    params = dev(f["params0"])
+    grads = eng.new_flat(eng.grad_len)
+    m, v = eng.new_flat(), eng.new_flat()
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    # gradient of step 0 without touching the parameters
+    eng.grads_only(params, grads, step, dev(f["x"][0]), dev(f["z1"][0]), dev(f["z2"][0]))
+    g = host(grads)
+    assert abs(g[eng.P] - f["loss0"]) <= LOSS_RTOL * abs(f["loss0"])
+    assert abs(g[eng.P + 1] - f["eval0"][1]) <= LOSS_RTOL * abs(f["eval0"][0])
+    assert abs(g[eng.P + 2] - f["eval0"][2]) <= LOSS_RTOL * abs(f["eval0"][0])
+    assert rel_err(g[:eng.P], f["grad0"]) <= GRAD_RTOL
+    assert np.array_equal(host(params), f["params0"].astype(np.float32).astype(np.float64))
+    step.zero_()
+    for s in range(meta["n_steps"]):
+        eng.train_step(params, grads, m, v, step, dev(f["x"][s]), dev(f["z1"][s]), dev(f["z2"][s]), lr)
+        l = host(grads)[eng.P]
+        assert abs(l - f["losses"][s]) <= LOSS_RTOL * abs(f["losses"][s]), (s, l, f["losses"][s])
+    assert int(step.item()) == meta["n_steps"]
+    assert np.max(np.abs(host(params) - f["params_final"])) <= 0.02 * lr
+    assert rel_err(host(m), f["m_final"]) <= 5e-5
+    assert rel_err(host(v), f["v_final"]) <= 5e-5
+
+
+@pytest.mark.parametrize("force_generic", [True, False])
+@pytest.mark.parametrize("name,B", [("c1_linear_L20", 1000), ("c1_linear_L2", 257), ("sigmoid_linear", 300),
+                                    ("c2_sigmoid_mlp", 515), ("c3_sphere_mlp", 1000), ("c4_linear_wide", 130),
+                                    ("linear_notdv", 64)])
+def test_seeded_grads_vs_oracle(name, B, force_generic):
+    """Ragged batch sizes (not multiples of the 64-row tiles) against the oracle on the same inputs."""
+    cfg, dk, _, lr = build(name)
+    p, x, z1, z2 = random_problem(cfg, dk, B)
+    loss, g = O.loss_and_grad(cfg, p, x, z1, z2)
+    eng = engine_for(cfg, B, force_generic=force_generic)
+    params = dev(O.flatten(cfg, p))
+    grads = eng.new_flat(eng.grad_len)
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    eng.grads_only(params, grads, step, dev(x), dev(z1), dev(z2))
+    got = host(grads)
+    assert abs(got[eng.P] - loss) <= LOSS_RTOL * abs(loss)
+    want = O.flatten(cfg, g)
+    assert rel_err(got[:eng.P], want) <= GRAD_RTOL
+    # per-leaf check so a small leaf (epsilon, epsilon_p, biases) cannot hide behind a large one
+    for n, (off, shape) in eng.leaves.items():
+        k = int(np.prod(shape))
+        assert rel_err(got[off:off + k], want[off:off + k]) <= 1e-4, n
+    ev = O.loss_eval(cfg, p, x, z1, z2)
+    out4 = host(eng.loss_eval(params, dev(x), dev(z1), dev(z2)))
+    assert abs(out4[0] - ev[0]) <= LOSS_RTOL * abs(ev[0])
+    assert abs(out4[1] - ev[1]) <= LOSS_RTOL * abs(ev[0]) and abs(out4[2] - ev[2]) <= LOSS_RTOL * abs(ev[0])
+    assert abs(out4[3] - float(np.asarray(ev[4]).reshape(-1)[0])) <= 1e-6
+
+
+@pytest.mark.parametrize("name", ["c1_linear_L20", "c2_sigmoid_mlp", "c3_sphere_mlp"])
+def test_forward_and_sampling(name):
+    cfg, dk, _, lr = build(name)
+    B = 200
+    p, x, z1, z2 = random_problem(cfg, dk, B)
+    eng = engine_for(cfg, B)
+    params = dev(O.flatten(cfg, p))
+    (xh, mu, lv, eps), _ = O.vae_forward(cfg, p, x, z1, z2)
+    gx, gmu = eng.forward(params, dev(x), dev(z1), dev(z2))
+    assert rel_err(host(gx), xh) <= 1e-5 and rel_err(host(gmu), mu) <= 1e-5
+    (xs, mus, _, _), c = O.vae_forward(cfg, p, None, z1, z2, sampling=True, epsilon=-0.7)
+    gxs, gmus = eng.forward(params, None, dev(z1), dev(z2), sampling=True, eps=-0.7)
+    assert rel_err(host(gxs), xs) <= 1e-5 and float(gmus.abs().max()) == 0.0
+    # fewer rows than the context's batch (eval uses print_batch_size rows, model.py:127)
+    gx2, _ = eng.forward(params, dev(x[:37]), dev(z1[:37]), dev(z2[:37]))
+    assert rel_err(host(gx2), xh[:37]) <= 1e-5
+
+
+def test_determinism_bitwise():
+    cfg, dk, _, lr = build("c2_sigmoid_mlp")
+    B = 4096
+    p, x, z1, z2 = random_problem(cfg, dk, B)
+    outs = []
+    for _ in range(2):
+        eng = engine_for(cfg, B)
+        params = dev(O.flatten(cfg, p))
+        grads = eng.new_flat(eng.grad_len)
+        step = torch.zeros(1, dtype=torch.int32, device="cuda")
+        eng.grads_only(params, grads, step, dev(x), dev(z1), dev(z2))
+        outs.append(grads.cpu().numpy().copy())
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_dp_shards_sum_to_full_batch():
+    """KAT-DP on the HIP path: shard gradients (global divisor) sum to the full-batch gradient."""
+    cfg, dk, _, lr = build("c2_sigmoid_mlp")
+    B, W = 2048, 4
+    p, x, z1, z2 = random_problem(cfg, dk, B)
+    params = dev(O.flatten(cfg, p))
+    full = engine_for(cfg, B)
+    g_full = full.new_flat(full.grad_len)
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    full.grads_only(params, g_full, step, dev(x), dev(z1), dev(z2))
+    acc = np.zeros(full.grad_len)
+    for w in range(W):
+        s = slice(w * B // W, (w + 1) * B // W)
+        eng = engine_for(cfg, B // W, world=W, rank=w, global_batch=B)
+        gw = eng.new_flat(eng.grad_len)
+        eng.grads_only(params, gw, step, dev(x[s]), dev(z1[s]), dev(z2[s]))
+        acc += host(gw)
+    assert rel_err(acc, host(g_full)) <= 2e-6
+
+
+def test_errors_are_reported_not_fatal():
+    from vae_training_amd import _lib
+    from vae_training_amd.engine import Engine
+    with pytest.raises(_lib.VaekError):
+        Engine(0, 4, 2)                                   # batch <= 0
+    with pytest.raises(_lib.VaekError):
+        Engine(8, 4, 300)                                 # latent_dim > 256
+    eng = Engine(64, 12, 20)
+    x = torch.zeros(65, 12, device="cuda")
+    with pytest.raises(_lib.VaekError):                   # more rows than the context's batch
+        eng.forward(eng.new_flat(), x, torch.zeros(65, 20, device="cuda"), torch.zeros(65, 12, device="cuda"))

@@ -1,0 +1,461 @@
+// C ABI of libvaek.so (include/vaek.h): context, flat parameter layout, workspace carving and the
+// layer-by-layer orchestration of VAE.train_step / VAE.loss / VAE.apply
+// (/root/reference/networks.py:87-101, :103-113, :61-84).
+#include <stdarg.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+#include "vaek_internal.h"
+
+namespace vaek {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static void add_net(vaek_ctx* c, Net& net, const char* name, int fan_in, const int* hidden, int n_hidden, int last) {
+    int k = fan_in;
+    for (int i = 0; i <= n_hidden; ++i) {
+        const int n = i < n_hidden ? hidden[i] : last;
+        Layer l;
+        l.n_in = k; l.n_out = n; l.w_off = c->P; l.relu = i < n_hidden;
+        char nm[64];
+        snprintf(nm, sizeof(nm), "%s/FC%d/kernel", name, i);
+        c->leaves.push_back({nm, c->P, k, n});
+        c->P += (int64_t)k * n;
+        snprintf(nm, sizeof(nm), "%s/FC%d/bias", name, i);
+        c->leaves.push_back({nm, c->P, 1, n});
+        c->P += n;
+        net.layers.push_back(l);
+        c->max_width = std::max(c->max_width, std::max(k, n));
+        k = n;
+    }
+}
+
+static size_t carve_acts(vaek_ctx* c, Net& net, size_t off) {
+    for (auto& l : net.layers) {
+        net.act_off.push_back(off);
+        off = align_up(off + (size_t)c->B * l.n_out * sizeof(float), 256);
+    }
+    return off;
+}
+
+static int check_ws(const vaek_ctx* c, const void* ws) {
+    if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255)) {
+        set_error("workspace must be a non-null, 256-byte aligned device pointer of vaek_workspace_bytes() bytes");
+        return VAEK_ERR_WORKSPACE;
+    }
+    (void)c;
+    return VAEK_OK;
+}
+
+template <typename T>
+static T* at(void* ws, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(ws) + off); }
+
+// ---- forward through one Dense/relu stack; `reparam` fuses networks.py:73-74 into the last layer
+static int net_forward(vaek_ctx* c, const Net& net, const float* params, const float* in, void* ws, int rows,
+                       bool reparam, const float* z1, hipStream_t st) {
+    const float* h = in;
+    for (size_t i = 0; i < net.layers.size(); ++i) {
+        const Layer& l = net.layers[i];
+        const float* w = params + l.w_off;
+        const float* b = w + (int64_t)l.n_in * l.n_out;
+        float* y = at<float>(ws, net.act_off[i]);
+        int rc;
+        if (reparam && i + 1 == net.layers.size())
+            rc = launch_dense_fwd_reparam(h, w, b, y, at<float>(ws, c->ws_samples), z1, params + c->off_epsp, rows,
+                                          l.n_in, l.n_out, st);
+        else
+            rc = launch_dense_fwd(h, w, b, y, rows, l.n_in, l.n_out, l.relu, st);
+        if (rc) return rc;
+        h = y;
+    }
+    return VAEK_OK;
+}
+
+// ---- backward through one stack.  d_out: gradient w.r.t. the last Dense output (lives in the
+// stack's last activation buffer).  dx_first: where dL/d(input) goes (nullptr: not needed).
+static int net_backward(vaek_ctx* c, const Net& net, const float* params, const float* in, float* d_out, void* ws,
+                        float* dx_first, bool accumulate_first, hipStream_t st) {
+    float* d = d_out;
+    float* gb[2] = {at<float>(ws, c->ws_gbuf0), at<float>(ws, c->ws_gbuf1)};
+    int tog = 0;
+    float* slabs = at<float>(ws, c->ws_slabs);
+    for (int i = (int)net.layers.size() - 1; i >= 0; --i) {
+        const Layer& l = net.layers[i];
+        const float* w = params + l.w_off;
+        const float* h_in = i == 0 ? in : at<float>(ws, net.act_off[i - 1]);
+        int rc = launch_dense_bwd_dw(h_in, d, slabs + l.w_off, c->P, c->S, c->rows_per_split, c->B, l.n_in, l.n_out, st);
+        if (rc) return rc;
+        if (i > 0) {
+            float* dx = gb[tog];
+            tog ^= 1;
+            rc = launch_dense_bwd_dx(d, w, h_in, dx, c->B, l.n_in, l.n_out, true, false, st);
+            if (rc) return rc;
+            d = dx;
+        } else if (dx_first) {
+            rc = launch_dense_bwd_dx(d, w, nullptr, dx_first, c->B, l.n_in, l.n_out, false, accumulate_first, st);
+            if (rc) return rc;
+        }
+    }
+    return VAEK_OK;
+}
+
+static int generic_grads(vaek_ctx* c, const float* params, int32_t* step_dev, const float* x, const float* z1,
+                         const float* z2, void* ws, hipStream_t st) {
+    const bool sig = c->cfg.sigmoid_decoder != 0;
+    const float inv_bt = (float)(1.0 / (double)c->Bt);
+    int rc;
+    if ((rc = net_forward(c, c->enc, params, x, ws, c->B, true, z1, st))) return rc;
+    const float* samples = at<float>(ws, c->ws_samples);
+    float* mu = at<float>(ws, c->enc.act_off.back());
+    if ((rc = net_forward(c, c->dec, params, samples, ws, c->B, false, nullptr, st))) return rc;
+    if (sig && (rc = net_forward(c, c->sig, params, samples, ws, c->B, false, nullptr, st))) return rc;
+    float* y_lin = at<float>(ws, c->dec.act_off.back());
+    float* y_sig = sig ? at<float>(ws, c->sig.act_off.back()) : nullptr;
+    ElboArgs e{};
+    e.x = x; e.y_lin = y_lin; e.y_sig = y_sig; e.z2 = z2; e.mu = mu;
+    e.eps_param = c->off_eps >= 0 ? params + c->off_eps : nullptr;
+    e.eps_cli = c->cfg.eps_cli;
+    e.d_lin = y_lin; e.d_sig = y_sig;
+    e.partial = at<float>(ws, c->ws_epart);
+    e.rows = c->B; e.D = c->D; e.L = c->L; e.S = c->Se; e.rows_per_split = c->rows_per_esplit;
+    e.inv_bt = inv_bt; e.step_dev = step_dev;
+    if ((rc = launch_elbo(e, st))) return rc;
+    float* dsamp = at<float>(ws, c->ws_dsamp);
+    if ((rc = net_backward(c, c->dec, params, samples, y_lin, ws, dsamp, false, st))) return rc;
+    if (sig && (rc = net_backward(c, c->sig, params, samples, y_sig, ws, dsamp, true, st))) return rc;
+    if ((rc = launch_reparam_bwd(dsamp, mu, z1, at<float>(ws, c->ws_rpart), c->B, c->L, c->Se, c->rows_per_esplit,
+                                 inv_bt, st)))
+        return rc;
+    return net_backward(c, c->enc, params, x, dsamp, ws, nullptr, false, st);
+}
+
+static int generic_finalize(vaek_ctx* c, const float* params, float* grads, float* params_rw, float* m, float* v,
+                            const int32_t* step_dev, float lr, void* ws, hipStream_t st) {
+    FinalizeArgs f{};
+    f.slabs = at<float>(ws, c->ws_slabs); f.slab_stride = c->P; f.S = c->S;
+    f.epart = at<float>(ws, c->ws_epart); f.rpart = at<float>(ws, c->ws_rpart); f.Se = c->Se;
+    f.P = c->P; f.off_epsp = c->off_epsp; f.off_eps = c->off_eps; f.L = c->L; f.D = c->D;
+    f.params = params; f.eps_cli = c->cfg.eps_cli;
+    f.rows_over_bt = (float)((double)c->B / (double)c->Bt); f.inv_bt = (float)(1.0 / (double)c->Bt);
+    f.rows = (float)c->B;
+    f.grads = grads; f.params_rw = params_rw; f.m = m; f.v = v; f.step_dev = step_dev; f.lr = lr;
+    return launch_finalize(f, st);
+}
+
+}  // namespace vaek
+
+using namespace vaek;
+
+extern "C" {
+
+int vaek_version(void) { return VAEK_VERSION; }
+const char* vaek_last_error(void) { return g_err; }
+
+int vaek_ctx_create(const vaek_config* cfg, vaek_ctx** out) {
+    if (!cfg || !out) { set_error("null argument"); return VAEK_ERR_INVALID; }
+    if (cfg->struct_size != (int32_t)sizeof(vaek_config)) {
+        set_error("vaek_config.struct_size %d != %zu (header/library mismatch)", cfg->struct_size, sizeof(vaek_config));
+        return VAEK_ERR_INVALID;
+    }
+    if (cfg->batch <= 0 || cfg->data_dim <= 0 || cfg->latent_dim <= 0 || cfg->n_enc_hidden < 0 ||
+        cfg->n_enc_hidden > VAEK_MAX_HIDDEN || cfg->n_dec_hidden < 0 || cfg->n_dec_hidden > VAEK_MAX_HIDDEN ||
+        cfg->world < 1 || cfg->rank < 0 || cfg->rank >= cfg->world) {
+        set_error("invalid geometry: batch=%d D=%d L=%d n_enc=%d n_dec=%d world=%d rank=%d", cfg->batch,
+                  cfg->data_dim, cfg->latent_dim, cfg->n_enc_hidden, cfg->n_dec_hidden, cfg->world, cfg->rank);
+        return VAEK_ERR_INVALID;
+    }
+    for (int i = 0; i < cfg->n_enc_hidden; ++i)
+        if (cfg->enc_hidden[i] <= 0) { set_error("encoder hidden width %d <= 0", cfg->enc_hidden[i]); return VAEK_ERR_INVALID; }
+    for (int i = 0; i < cfg->n_dec_hidden; ++i)
+        if (cfg->dec_hidden[i] <= 0) { set_error("decoder hidden width %d <= 0", cfg->dec_hidden[i]); return VAEK_ERR_INVALID; }
+    if (cfg->latent_dim > 256) { set_error("latent_dim %d > 256 unsupported", cfg->latent_dim); return VAEK_ERR_INVALID; }
+    if (cfg->dtype != VAEK_F32 && cfg->dtype != VAEK_BF16) { set_error("unknown dtype %d", cfg->dtype); return VAEK_ERR_INVALID; }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device visible: libvaek.so has no CPU fallback");
+        return VAEK_ERR_NO_DEVICE;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) { set_error("device %d out of range (%d visible)", cfg->device, ndev); return VAEK_ERR_INVALID; }
+    hipDeviceProp_t prop;
+    VAEK_HIP_CHECK(hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; this library is built for gfx950 (MI355X) only", cfg->device, prop.gcnArchName);
+        return VAEK_ERR_NO_DEVICE;
+    }
+
+    vaek_ctx* c = new (std::nothrow) vaek_ctx();
+    if (!c) { set_error("out of host memory"); return VAEK_ERR_INVALID; }
+    c->cfg = *cfg;
+    c->B = cfg->batch; c->D = cfg->data_dim; c->L = cfg->latent_dim;
+    c->Bt = cfg->global_batch > 0 ? cfg->global_batch : (int64_t)cfg->batch * cfg->world;
+    c->P = 0; c->max_width = std::max(c->D, c->L);
+    c->n_cu = prop.multiProcessorCount;
+    add_net(c, c->enc, "Encoder", c->D, cfg->enc_hidden, cfg->n_enc_hidden, c->L);
+    add_net(c, c->dec, "Decoder", c->L, cfg->dec_hidden, cfg->n_dec_hidden, c->D);
+    if (cfg->sigmoid_decoder) add_net(c, c->sig, "SigDecoder", c->L, cfg->dec_hidden, cfg->n_dec_hidden, c->D);
+    c->off_epsp = c->P;
+    c->leaves.push_back({"epsilon_p", c->P, 1, c->L});
+    c->P += c->L;
+    c->off_eps = -1;
+    if (cfg->tunable_eps) {
+        c->off_eps = c->P;
+        c->leaves.push_back({"epsilon", c->P, 1, 1});
+        c->P += 1;
+    }
+    // batch splits: dW|db GEMM slabs sized so that (tiles x S) fills the chip; elementwise
+    // partials one per <= 1024 row-blocks
+    int max_tiles = 1;
+    auto tiles = [&](const Net& n) {
+        for (auto& l : n.layers) max_tiles = std::max(max_tiles, ((l.n_in + 1 + 63) / 64) * ((l.n_out + 63) / 64));
+    };
+    tiles(c->enc); tiles(c->dec); tiles(c->sig);
+    int s_target = std::min(256, std::max(4, 1024 / max_tiles));
+    c->rows_per_split = std::max(64, (int)align_up((size_t)(c->B + s_target - 1) / s_target, 64));
+    c->S = (c->B + c->rows_per_split - 1) / c->rows_per_split;
+    c->rows_per_esplit = std::max(64, (int)align_up((size_t)(c->B + 1023) / 1024, 64));
+    c->Se = (c->B + c->rows_per_esplit - 1) / c->rows_per_esplit;
+
+    size_t off = 0;
+    off = carve_acts(c, c->enc, off);
+    c->ws_samples = off; off = align_up(off + (size_t)c->B * c->L * sizeof(float), 256);
+    off = carve_acts(c, c->dec, off);
+    off = carve_acts(c, c->sig, off);
+    c->ws_dsamp = off; off = align_up(off + (size_t)c->B * c->L * sizeof(float), 256);
+    c->ws_gbuf0 = off; off = align_up(off + (size_t)c->B * c->max_width * sizeof(float), 256);
+    c->ws_gbuf1 = off; off = align_up(off + (size_t)c->B * c->max_width * sizeof(float), 256);
+    c->ws_slabs = off; off = align_up(off + (size_t)c->S * c->P * sizeof(float), 256);
+    c->ws_epart = off; off = align_up(off + (size_t)c->Se * 4 * sizeof(float), 256);
+    c->ws_rpart = off; off = align_up(off + (size_t)c->Se * c->L * sizeof(float), 256);
+    c->fused = !cfg->force_generic && fused_supported(c);
+    c->ws_fused = off; off = align_up(off + fused_workspace_bytes(c), 256);
+    c->ws_total = off;
+    *out = c;
+    return VAEK_OK;
+}
+
+int vaek_ctx_destroy(vaek_ctx* ctx) {
+    if (!ctx) return VAEK_OK;
+    vaek_comm_destroy(ctx);
+    delete ctx;
+    return VAEK_OK;
+}
+
+int vaek_param_count(const vaek_ctx* ctx, int64_t* P) {
+    if (!ctx || !P) { set_error("null argument"); return VAEK_ERR_INVALID; }
+    *P = ctx->P;
+    return VAEK_OK;
+}
+int vaek_grad_len(const vaek_ctx* ctx, int64_t* n) {
+    if (!ctx || !n) { set_error("null argument"); return VAEK_ERR_INVALID; }
+    *n = ctx->P + kExtra;
+    return VAEK_OK;
+}
+int vaek_leaf_count(const vaek_ctx* ctx, int32_t* n) {
+    if (!ctx || !n) { set_error("null argument"); return VAEK_ERR_INVALID; }
+    *n = (int32_t)ctx->leaves.size();
+    return VAEK_OK;
+}
+int vaek_leaf_info(const vaek_ctx* ctx, int32_t leaf, char* name, int32_t name_cap, int64_t* offset, int32_t* rows,
+                   int32_t* cols) {
+    if (!ctx || leaf < 0 || leaf >= (int32_t)ctx->leaves.size()) { set_error("leaf index out of range"); return VAEK_ERR_INVALID; }
+    const Leaf& l = ctx->leaves[leaf];
+    if (name && name_cap > 0) { strncpy(name, l.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (offset) *offset = l.offset;
+    if (rows) *rows = l.rows;
+    if (cols) *cols = l.cols;
+    return VAEK_OK;
+}
+int vaek_workspace_bytes(const vaek_ctx* ctx, size_t* bytes) {
+    if (!ctx || !bytes) { set_error("null argument"); return VAEK_ERR_INVALID; }
+    *bytes = ctx->ws_total;
+    return VAEK_OK;
+}
+int vaek_uses_fused_path(const vaek_ctx* ctx, int32_t* fused) {
+    if (!ctx || !fused) { set_error("null argument"); return VAEK_ERR_INVALID; }
+    *fused = ctx->fused ? 1 : 0;
+    return VAEK_OK;
+}
+
+// ---- building blocks ------------------------------------------------------------------------
+int vaek_dense_fwd(vaek_ctx* ctx, const float* x, const float* w, const float* b, float* y, int32_t rows,
+                   int32_t n_in, int32_t n_out, int32_t act, void* stream) {
+    if (!ctx || !x || !w || !y || rows <= 0 || n_in <= 0 || n_out <= 0 || (act != VAEK_ACT_NONE && act != VAEK_ACT_RELU)) {
+        set_error("vaek_dense_fwd: invalid argument");
+        return VAEK_ERR_INVALID;
+    }
+    return launch_dense_fwd(x, w, b, y, rows, n_in, n_out, act == VAEK_ACT_RELU, (hipStream_t)stream);
+}
+
+int vaek_dense_bwd_dx(vaek_ctx* ctx, const float* dy, const float* w, const float* x_post, float* dx, int32_t rows,
+                      int32_t n_in, int32_t n_out, int32_t act, int32_t accumulate, void* stream) {
+    if (!ctx || !dy || !w || !dx || rows <= 0 || n_in <= 0 || n_out <= 0 || (act == VAEK_ACT_RELU && !x_post) ||
+        (act != VAEK_ACT_NONE && act != VAEK_ACT_RELU)) {
+        set_error("vaek_dense_bwd_dx: invalid argument");
+        return VAEK_ERR_INVALID;
+    }
+    return launch_dense_bwd_dx(dy, w, x_post, dx, rows, n_in, n_out, act == VAEK_ACT_RELU, accumulate != 0,
+                               (hipStream_t)stream);
+}
+
+int vaek_dense_bwd_dw(vaek_ctx* ctx, const float* x, const float* dy, float* dwb, int32_t rows, int32_t n_in,
+                      int32_t n_out, void* workspace, void* stream) {
+    if (!ctx || !x || !dy || !dwb || rows <= 0 || n_in <= 0 || n_out <= 0) {
+        set_error("vaek_dense_bwd_dw: invalid argument");
+        return VAEK_ERR_INVALID;
+    }
+    int rc = check_ws(ctx, workspace);
+    if (rc) return rc;
+    const int64_t n = (int64_t)(n_in + 1) * n_out;
+    const int rps = std::max(64, (int)align_up((size_t)(rows + ctx->S - 1) / ctx->S, 64));
+    const int S = (rows + rps - 1) / rps;
+    if ((size_t)S * n * sizeof(float) > (size_t)ctx->S * ctx->P * sizeof(float)) {
+        set_error("vaek_dense_bwd_dw: layer (%d+1)x%d does not fit this context's slab workspace", n_in, n_out);
+        return VAEK_ERR_WORKSPACE;
+    }
+    float* slabs = at<float>(workspace, ctx->ws_slabs);
+    if ((rc = launch_dense_bwd_dw(x, dy, slabs, n, S, rps, rows, n_in, n_out, (hipStream_t)stream))) return rc;
+    return launch_sum_slabs(slabs, n, S, dwb, n, (hipStream_t)stream);
+}
+
+int vaek_elbo_fwd_bwd(vaek_ctx* ctx, const float* x, const float* x_hat_lin, const float* x_hat_sig, const float* z2,
+                      const float* mu, const float* logvar_e, float eps, float* d_lin, float* d_sig, float* out4,
+                      int32_t rows, int32_t data_dim, int32_t latent_dim, int64_t batch_total, void* workspace,
+                      void* stream) {
+    if (!ctx || !x || !x_hat_lin || !z2 || !mu || !logvar_e || !out4 || rows <= 0 || data_dim <= 0 || latent_dim <= 0 ||
+        (d_lin && x_hat_sig && !d_sig)) {
+        set_error("vaek_elbo_fwd_bwd: invalid argument");
+        return VAEK_ERR_INVALID;
+    }
+    int rc = check_ws(ctx, workspace);
+    if (rc) return rc;
+    const int rpe = std::max(64, (int)align_up((size_t)(rows + 1023) / 1024, 64));
+    const int Se = (rows + rpe - 1) / rpe;
+    if (Se > ctx->Se) { set_error("vaek_elbo_fwd_bwd: rows %d exceed this context's batch %d", rows, ctx->B); return VAEK_ERR_WORKSPACE; }
+    const int64_t bt = batch_total > 0 ? batch_total : rows;
+    ElboArgs e{};
+    e.x = x; e.y_lin = x_hat_lin; e.y_sig = x_hat_sig; e.z2 = z2; e.mu = mu;
+    e.eps_param = nullptr; e.eps_cli = eps; e.d_lin = d_lin; e.d_sig = d_sig;
+    e.partial = at<float>(workspace, ctx->ws_epart);
+    e.rows = rows; e.D = data_dim; e.L = latent_dim; e.S = Se; e.rows_per_split = rpe;
+    e.inv_bt = (float)(1.0 / (double)bt); e.step_dev = nullptr;
+    if ((rc = launch_elbo(e, (hipStream_t)stream))) return rc;
+    return launch_elbo_out4(e.partial, Se, logvar_e, latent_dim, data_dim, eps, (float)rows, e.inv_bt, out4,
+                            (hipStream_t)stream);
+}
+
+int vaek_adam_step(vaek_ctx* ctx, float* params, const float* grads, float* m, float* v, int64_t n, float lr,
+                   int32_t step, const int32_t* step_dev, float grad_scale, void* stream) {
+    if (!ctx || !params || !grads || !m || !v || n < 0 || (!step_dev && step < 1)) {
+        set_error("vaek_adam_step: invalid argument");
+        return VAEK_ERR_INVALID;
+    }
+    return launch_adam(params, grads, m, v, n, lr, step, step_dev, grad_scale, (hipStream_t)stream);
+}
+
+// ---- the hot path ----------------------------------------------------------------------------
+int vaek_train_step_grads_only(vaek_ctx* ctx, const float* params, float* grads, int32_t* step_dev, const float* x,
+                               const float* z1, const float* z2, void* workspace, void* stream) {
+    if (!ctx || !params || !grads || !step_dev || !x || !z1 || !z2) { set_error("vaek_train_step_grads_only: null argument"); return VAEK_ERR_INVALID; }
+    int rc = check_ws(ctx, workspace);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (ctx->fused)
+        return fused_train_step(ctx, const_cast<float*>(params), grads, nullptr, nullptr, step_dev, x, z1, z2, 0.f, false,
+                                workspace, st);
+    if ((rc = generic_grads(ctx, params, step_dev, x, z1, z2, workspace, st))) return rc;
+    return generic_finalize(ctx, params, grads, nullptr, nullptr, nullptr, nullptr, 0.f, workspace, st);
+}
+
+int vaek_train_step_apply(vaek_ctx* ctx, float* params, const float* grads, float* m, float* v,
+                          const int32_t* step_dev, float lr, void* stream) {
+    if (!ctx || !params || !grads || !m || !v || !step_dev) { set_error("vaek_train_step_apply: null argument"); return VAEK_ERR_INVALID; }
+    return launch_adam(params, grads, m, v, ctx->P, lr, 0, step_dev, 1.f, (hipStream_t)stream);
+}
+
+int vaek_train_step(vaek_ctx* ctx, float* params, float* grads, float* m, float* v, int32_t* step_dev, const float* x,
+                    const float* z1, const float* z2, float lr, void* workspace, void* stream) {
+    if (!ctx || !params || !grads || !m || !v || !step_dev || !x || !z1 || !z2) { set_error("vaek_train_step: null argument"); return VAEK_ERR_INVALID; }
+    int rc = check_ws(ctx, workspace);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (ctx->cfg.world > 1) {
+        if (!ctx->comm.ready) {
+            set_error("vaek_train_step: world=%d but no communicator; call vaek_comm_init or use "
+                      "vaek_train_step_grads_only + all-reduce + vaek_train_step_apply", ctx->cfg.world);
+            return VAEK_ERR_COMM;
+        }
+        if ((rc = vaek_train_step_grads_only(ctx, params, grads, step_dev, x, z1, z2, workspace, stream))) return rc;
+        if ((rc = vaek_comm_allreduce(ctx, grads, ctx->P + kExtra, stream))) return rc;
+        return vaek_train_step_apply(ctx, params, grads, m, v, step_dev, lr, stream);
+    }
+    if (ctx->fused) return fused_train_step(ctx, params, grads, m, v, step_dev, x, z1, z2, lr, true, workspace, st);
+    if ((rc = generic_grads(ctx, params, step_dev, x, z1, z2, workspace, st))) return rc;
+    return generic_finalize(ctx, params, grads, params, m, v, step_dev, lr, workspace, st);
+}
+
+int vaek_loss_eval(vaek_ctx* ctx, const float* params, const float* x, const float* z1, const float* z2, float* out4,
+                   void* workspace, void* stream) {
+    if (!ctx || !params || !x || !z1 || !z2 || !out4) { set_error("vaek_loss_eval: null argument"); return VAEK_ERR_INVALID; }
+    int rc = check_ws(ctx, workspace);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    vaek_ctx* c = ctx;
+    const bool sig = c->cfg.sigmoid_decoder != 0;
+    if ((rc = net_forward(c, c->enc, params, x, workspace, c->B, true, z1, st))) return rc;
+    const float* samples = at<float>(workspace, c->ws_samples);
+    if ((rc = net_forward(c, c->dec, params, samples, workspace, c->B, false, nullptr, st))) return rc;
+    if (sig && (rc = net_forward(c, c->sig, params, samples, workspace, c->B, false, nullptr, st))) return rc;
+    ElboArgs e{};
+    e.x = x; e.y_lin = at<float>(workspace, c->dec.act_off.back());
+    e.y_sig = sig ? at<float>(workspace, c->sig.act_off.back()) : nullptr;
+    e.z2 = z2; e.mu = at<float>(workspace, c->enc.act_off.back());
+    e.eps_param = c->off_eps >= 0 ? params + c->off_eps : nullptr; e.eps_cli = c->cfg.eps_cli;
+    e.partial = at<float>(workspace, c->ws_epart);
+    e.rows = c->B; e.D = c->D; e.L = c->L; e.S = c->Se; e.rows_per_split = c->rows_per_esplit;
+    e.inv_bt = (float)(1.0 / (double)c->B);     // VAE.loss is a plain mean over the eval batch
+    if ((rc = launch_elbo(e, st))) return rc;
+    return launch_eval_out4(e.partial, c->Se, params, c->off_epsp, c->off_eps, c->L, c->D, c->cfg.eps_cli, (float)c->B,
+                            e.inv_bt, out4, st);
+}
+
+int vaek_forward(vaek_ctx* ctx, const float* params, const float* x, const float* z1, const float* z2,
+                 int32_t sampling, float eps, float* x_hat, float* mu_out, int32_t rows, void* workspace, void* stream) {
+    if (!ctx || !params || !z1 || !z2 || !x_hat || (!sampling && !x) || rows <= 0) { set_error("vaek_forward: invalid argument"); return VAEK_ERR_INVALID; }
+    if (rows > ctx->B) { set_error("vaek_forward: rows %d exceed this context's batch %d", rows, ctx->B); return VAEK_ERR_WORKSPACE; }
+    int rc = check_ws(ctx, workspace);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    vaek_ctx* c = ctx;
+    const bool sig = c->cfg.sigmoid_decoder != 0;
+    const float* samples = z1;                      // sampling: mu = 0, logvar_e = 0 -> samples = z1
+    if (!sampling) {
+        if ((rc = net_forward(c, c->enc, params, x, workspace, rows, true, z1, st))) return rc;
+        samples = at<float>(workspace, c->ws_samples);
+        if (mu_out)
+            VAEK_HIP_CHECK(hipMemcpyAsync(mu_out, at<float>(workspace, c->enc.act_off.back()),
+                                          (size_t)rows * c->L * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else if (mu_out) {
+        VAEK_HIP_CHECK(hipMemsetAsync(mu_out, 0, (size_t)rows * c->L * sizeof(float), st));
+    }
+    if ((rc = net_forward(c, c->dec, params, samples, workspace, rows, false, nullptr, st))) return rc;
+    if (sig && (rc = net_forward(c, c->sig, params, samples, workspace, rows, false, nullptr, st))) return rc;
+    const float* eps_param = (!sampling && c->off_eps >= 0) ? params + c->off_eps : nullptr;
+    const float eps_val = sampling ? eps : c->cfg.eps_cli;
+    return launch_add_noise(at<float>(workspace, c->dec.act_off.back()),
+                            sig ? at<float>(workspace, c->sig.act_off.back()) : nullptr, z2, eps_param, eps_val, x_hat,
+                            (int64_t)rows * c->D, st);
+}
+
+}  // extern "C"

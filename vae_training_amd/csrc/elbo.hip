@@ -1,0 +1,283 @@
+// Elementwise / reduction kernels of the ELBO train step (K4-K6 of SURVEY.md 7.1), float32.
+//   elbo_kernel         networks.py:81-83 (decoder noise) + :94-98 (Dkl, mse, mean) and dL/dx_hat
+//   reparam_bwd_kernel  backward of networks.py:73-74 (samples = mu + exp(lv/2) z1) + KL's mu term
+//   finalize_kernel     fixed-order sum of the per-split partial slabs -> flat gradient (+ fused Adam)
+//   adam_kernel         flax.optim.Adam.apply_gradient, networks.py:100
+// All batch reductions are two-stage (per-split partials, then a fixed-order sum): no float
+// atomics, so results are bitwise repeatable run to run.
+#include "vaek_internal.h"
+
+namespace vaek {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// Sum over a 256-thread block; result valid in thread 0.  red: >= 4 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += red[i];
+    }
+    return r;
+}
+__device__ __forceinline__ float sigmoidf_(float a) { return 1.f / (1.f + expf(-a)); }
+
+template <bool SIG, bool GRADS>
+__global__ __launch_bounds__(256) void elbo_kernel(const ElboArgs a) {
+    __shared__ float red[8];
+    const int s = blockIdx.x;
+    const long long r0 = (long long)s * a.rows_per_split;
+    const long long r1 = min((long long)a.rows, r0 + a.rows_per_split);
+    const float eps = a.eps_param ? a.eps_param[0] * a.eps_cli : a.eps_cli;
+    const float inv_var = expf(-eps), sigma = expf(0.5f * eps);
+    const float dscale = inv_var * a.inv_bt;
+    float mse = 0.f, deps = 0.f, musq = 0.f;
+    if (r0 < r1) {
+        const long long e0 = r0 * a.D, e1 = r1 * a.D;
+        for (long long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+            const float z = a.z2[e];
+            float xh = a.y_lin[e] + sigma * z;
+            float sg = 0.f;
+            if (SIG) { sg = sigmoidf_(a.y_sig[e]); xh += sg; }
+            const float r = xh - a.x[e];
+            const float q = r * r * inv_var;
+            mse += 0.5f * q;
+            deps += -0.5f * q + 0.5f * sigma * z * r * inv_var;
+            if (GRADS) {
+                const float d = r * dscale;
+                a.d_lin[e] = d;
+                if (SIG) a.d_sig[e] = d * sg * (1.f - sg);
+            }
+        }
+        const long long l0 = r0 * a.L, l1 = r1 * a.L;
+        for (long long e = l0 + threadIdx.x; e < l1; e += blockDim.x) {
+            const float m = a.mu[e];
+            musq += m * m;
+        }
+    }
+    const float t_mse = block_sum(mse, red);
+    const float t_deps = block_sum(deps, red);
+    const float t_musq = block_sum(musq, red);
+    if (threadIdx.x == 0) {
+        float* p = a.partial + (long long)s * 4;
+        p[0] = t_mse; p[1] = t_musq; p[2] = t_deps; p[3] = 0.f;
+        if (s == 0 && a.step_dev) a.step_dev[0] += 1;
+    }
+}
+
+int launch_elbo(const ElboArgs& a, hipStream_t st) {
+    const bool sig = a.y_sig != nullptr, grads = a.d_lin != nullptr;
+    dim3 grid(a.S), block(256);
+    if (sig && grads) hipLaunchKernelGGL((elbo_kernel<true, true>), grid, block, 0, st, a);
+    else if (sig) hipLaunchKernelGGL((elbo_kernel<true, false>), grid, block, 0, st, a);
+    else if (grads) hipLaunchKernelGGL((elbo_kernel<false, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((elbo_kernel<false, false>), grid, block, 0, st, a);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+// block s: rows [r0, r1); thread t -> column t % L, row group t / L (threads >= G*L idle)
+__global__ __launch_bounds__(256) void reparam_bwd_kernel(float* dsamp, const float* mu, const float* z1,
+                                                         float* partial, int rows, int L,
+                                                         int rows_per_split, float inv_bt) {
+    extern __shared__ float sh[];   // 256 floats
+    const int s = blockIdx.x;
+    const int r0 = s * rows_per_split, r1 = min(rows, r0 + rows_per_split);
+    const int G = 256 / L;          // L <= 256 checked on the host
+    const int col = threadIdx.x % L, grp = threadIdx.x / L;
+    float acc = 0.f;
+    if (grp < G) {
+        for (int r = r0 + grp; r < r1; r += G) {
+            const long long o = (long long)r * L + col;
+            const float d = dsamp[o];
+            acc += d * z1[o];
+            dsamp[o] = d + mu[o] * inv_bt;
+        }
+    }
+    sh[threadIdx.x] = grp < G ? acc : 0.f;
+    __syncthreads();
+    if (threadIdx.x < L) {
+        float t = 0.f;
+        for (int g2 = 0; g2 < G; ++g2) t += sh[g2 * L + threadIdx.x];
+        partial[(long long)s * L + threadIdx.x] = t;
+    }
+}
+
+int launch_reparam_bwd(float* dsamp, const float* mu, const float* z1, float* partial,
+                       int rows, int L, int S, int rows_per_split, float inv_bt, hipStream_t st) {
+    if (L > 256) { set_error("latent_dim %d > 256 not supported by reparam_bwd", L); return VAEK_ERR_INVALID; }
+    hipLaunchKernelGGL(reparam_bwd_kernel, dim3(S), dim3(256), 256 * sizeof(float), st, dsamp, mu, z1, partial,
+                       rows, L, rows_per_split, inv_bt);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+// Bias corrections 1 - beta^t, accurate to ~2e-7 relative for every t >= 1 in float32.
+__device__ __forceinline__ void adam_apply(float& p, float g, float& m, float& v, float lr, float bc1, float bc2) {
+    // (1 - beta) is formed in double first, as Python does for flax's float hyper-parameters:
+    // 1.f - 0.999f is off by 4.7e-5 relative
+    m = kAdamB1 * m + (float)(1.0 - 0.9) * g;
+    v = kAdamB2 * v + (float)(1.0 - 0.999) * g * g;
+    const float mh = m / bc1, vh = v / bc2;
+    p = p - lr * mh / (sqrtf(vh) + kAdamEps);
+}
+__device__ __forceinline__ void adam_bias_corrections(int t, float& bc1, float& bc2) {
+    // log(0.9), log(0.999) in float; -expm1(t log b) keeps full relative precision at small t
+    bc1 = -expm1f((float)t * -0.10536051565782628f);
+    bc2 = -expm1f((float)t * -0.0010005003335835335f);
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(const FinalizeArgs a) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = a.P + kExtra;
+    if (i >= n) return;
+    float g = 0.f;
+    if (i < a.P) {
+        if (i == a.off_eps) {
+            float d = 0.f;
+            for (int s = 0; s < a.Se; ++s) d += a.epart[s * 4 + 2];
+            // eps = param * eps_cli, networks.py:71; + 0.5 per (row, d) element is the constant part
+            g = a.eps_cli * (d + 0.5f * a.rows * (float)a.D) * a.inv_bt;
+        } else if (i >= a.off_epsp && i < a.off_epsp + a.L) {
+            for (int s = 0; s < a.Se; ++s) g += a.rpart[(long long)s * a.L + (i - a.off_epsp)];
+            const float lv = a.params[i];
+            g = 0.5f * expf(0.5f * lv) * g - 0.5f * (1.f - expf(lv)) * a.rows_over_bt;
+        } else {
+            for (int s = 0; s < a.S; ++s) g += a.slabs[(long long)s * a.slab_stride + i];
+        }
+    } else if (i == a.P || i == a.P + 1 || i == a.P + 2) {
+        float smse = 0.f, smusq = 0.f;
+        for (int s = 0; s < a.Se; ++s) {
+            smse += a.epart[s * 4 + 0];
+            smusq += a.epart[s * 4 + 1];
+        }
+        float klc = 0.f;   // sum_l (1 + lv - e^lv)
+        for (int l = 0; l < a.L; ++l) { const float lv = a.params[a.off_epsp + l]; klc += 1.f + lv - expf(lv); }
+        const float eps = a.off_eps >= 0 ? a.params[a.off_eps] * a.eps_cli : a.eps_cli;
+        const float dkl = (0.5f * smusq - 0.5f * a.rows * klc) * a.inv_bt;
+        const float mse = (smse + 0.5f * a.rows * (float)a.D * (kLog2Pi + eps)) * a.inv_bt;
+        g = (i == a.P) ? dkl + mse : (i == a.P + 1 ? dkl : mse);
+    }
+    a.grads[i] = g;
+    if (a.params_rw && i < a.P) {
+        float bc1, bc2;
+        adam_bias_corrections(a.step_dev[0], bc1, bc2);
+        float p = a.params_rw[i], m = a.m[i], v = a.v[i];
+        adam_apply(p, g, m, v, a.lr, bc1, bc2);
+        a.params_rw[i] = p; a.m[i] = m; a.v[i] = v;
+    }
+}
+
+int launch_finalize(const FinalizeArgs& a, hipStream_t st) {
+    const long long n = a.P + kExtra;
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* params, const float* grads, float* m, float* v,
+                                                  long long n, float lr, int step, const int32_t* step_dev,
+                                                  float grad_scale) {
+    float bc1, bc2;
+    adam_bias_corrections(step_dev ? step_dev[0] : step, bc1, bc2);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float p = params[i], mm = m[i], vv = v[i];
+        adam_apply(p, grads[i] * grad_scale, mm, vv, lr, bc1, bc2);
+        params[i] = p; m[i] = mm; v[i] = vv;
+    }
+}
+
+int launch_adam(float* params, const float* grads, float* m, float* v, int64_t n, float lr, int step,
+                const int32_t* step_dev, float grad_scale, hipStream_t st) {
+    if (n <= 0) return VAEK_OK;
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, params, grads, m, v, (long long)n, lr, step,
+                       step_dev, grad_scale);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+__global__ __launch_bounds__(256) void add_noise_kernel(const float* y_lin, const float* y_sig, const float* z2,
+                                                       const float* eps_param, float eps_cli, float* x_hat,
+                                                       long long n) {
+    const float eps = eps_param ? eps_param[0] * eps_cli : eps_cli;
+    const float sigma = expf(0.5f * eps);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = y_lin[i] + sigma * z2[i];
+        if (y_sig) v += sigmoidf_(y_sig[i]);
+        x_hat[i] = v;
+    }
+}
+
+int launch_add_noise(const float* y_lin, const float* y_sig, const float* z2, const float* eps_param,
+                     float eps_cli, float* x_hat, int64_t n, hipStream_t st) {
+    if (n <= 0) return VAEK_OK;
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(add_noise_kernel, dim3(blocks), dim3(256), 0, st, y_lin, y_sig, z2, eps_param, eps_cli,
+                       x_hat, (long long)n);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+// single block: sums S partials of {mse, musq, deps}; lv / eps from explicit pointers or values
+__global__ __launch_bounds__(64) void out4_kernel(const float* partial, int S, const float* lv,
+                                                 const float* eps_param, float eps_cli, int L, int D, float rows,
+                                                 float inv_bt, float* out4, int want_deps) {
+    if (threadIdx.x != 0) return;
+    float smse = 0.f, smusq = 0.f, sdeps = 0.f;
+    for (int s = 0; s < S; ++s) {
+        smse += partial[s * 4 + 0];
+        smusq += partial[s * 4 + 1];
+        sdeps += partial[s * 4 + 2];
+    }
+    float klc = 0.f;
+    for (int l = 0; l < L; ++l) klc += 1.f + lv[l] - expf(lv[l]);
+    const float eps = eps_param ? eps_param[0] * eps_cli : eps_cli;
+    const float dkl = (0.5f * smusq - 0.5f * rows * klc) * inv_bt;
+    const float mse = (smse + 0.5f * rows * (float)D * (kLog2Pi + eps)) * inv_bt;
+    out4[0] = dkl + mse; out4[1] = dkl; out4[2] = mse;
+    out4[3] = want_deps ? (sdeps + 0.5f * rows * (float)D) * inv_bt : eps;
+}
+
+int launch_elbo_out4(const float* partial, int S, const float* lv, int L, int D,
+                     float eps, float rows, float inv_bt, float* out4, hipStream_t st) {
+    hipLaunchKernelGGL(out4_kernel, dim3(1), dim3(64), 0, st, partial, S, lv,
+                       (const float*)nullptr, eps, L, D, rows, inv_bt, out4, 1);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+int launch_eval_out4(const float* partial, int S, const float* params, int64_t off_epsp,
+                     int64_t off_eps, int L, int D, float eps_cli, float rows, float inv_bt, float* out4,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(out4_kernel, dim3(1), dim3(64), 0, st, partial, S, params + off_epsp,
+                       off_eps >= 0 ? params + off_eps : (const float*)nullptr, eps_cli, L, D, rows, inv_bt,
+                       out4, 0);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* slabs, long long stride, int S, float* out,
+                                                       long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float g = 0.f;
+    for (int s = 0; s < S; ++s) g += slabs[(long long)s * stride + i];
+    out[i] = g;
+}
+
+int launch_sum_slabs(const float* slabs, int64_t stride, int S, float* out, int64_t n, hipStream_t st) {
+    if (n <= 0) return VAEK_OK;
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slabs,
+                       (long long)stride, S, out, (long long)n);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+}  // namespace vaek

@@ -1,0 +1,210 @@
+// Layer-by-layer Dense kernels (K1-K3 of SURVEY.md 7.1), float32 in / float32 accumulate on the
+// gfx950 f32 matrix cores: v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf chain, so this
+// path carries the 1e-5-relative-ELBO parity contract for every layer shape.
+//
+// One kernel template, three uses (flax.nn.Dense call sites networks.py:32-34 and their
+// value_and_grad transposes, networks.py:99):
+//   forward   Y[B,N]   = act(X[B,K] W[K,N] + b)            A: k-contiguous, B: n-contiguous
+//   dX        dX[B,K]  = (dY[B,N] W^T) * relu'(X)          A: k-contiguous, B: k-contiguous
+//   dW | db   G[K+1,N] = [X | 1]^T dY   split over batch   A: m-contiguous (+ones row), B: n-contiguous
+// Block = 256 threads = 4 waves, 64x64 output tile, each wave one 32x32 MFMA tile, BK = 16.
+// LDS tiles are k-major ([k][m] / [k][n]) so every MFMA operand read is 32 consecutive floats
+// (conflict-free ds_read_b32); the next K-tile is fetched into registers while the MFMAs of the
+// current one run (issue-early / write-late staging).
+#include "vaek_internal.h"
+
+namespace vaek {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BM = 64, BN = 64, BK = 16, LDS_STRIDE = 68, NT = 256;
+
+enum { EPI_FWD = 0, EPI_REPARAM = 1, EPI_DX = 2, EPI_DW = 3 };
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    int M, N, K;              // logical dims, K = reduction
+    int lda, ldb, ldc;
+    int a_mem;                // A, m-contiguous mode: number of real m columns in memory (ones row at index a_mem)
+    const float* bias; int relu;
+    const float* aux;         // DX: x_post [M, ldc]; REPARAM: z1 [M, ldc]
+    float* C2;                // REPARAM: samples
+    const float* lv;          // REPARAM: logvar_e [N]
+    int accumulate;
+    int k_per_split; long long slab_stride;   // DW
+};
+
+// (mn, k) element at p[mn*ld + k]; tile 64 (mn) x 16 (k); thread -> row t>>2, 4 consecutive k.
+__device__ __forceinline__ void fetch_kcont(const float* __restrict__ p, int ld, int mn0, int MN, int k0,
+                                            int kend, bool vec_ok, float (&v)[4]) {
+    const int t = threadIdx.x;
+    const int mn = mn0 + (t >> 2);
+    const int k = k0 + (t & 3) * 4;
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (mn < MN) {
+        const float* q = p + (long long)mn * ld + k;
+        if (vec_ok && k + 3 < kend) {
+            const float4 f = *reinterpret_cast<const float4*>(q);
+            v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (k + c < kend) v[c] = q[c];
+        }
+    }
+}
+__device__ __forceinline__ void store_kcont(float* s, const float (&v)[4]) {
+    const int t = threadIdx.x;
+    const int mn = t >> 2, k = (t & 3) * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s[(k + c) * LDS_STRIDE + mn] = v[c];
+}
+// (mn, k) element at p[k*ld + mn]; tile 16 (k) x 64 (mn); thread -> k row t>>4, 4 consecutive mn.
+// mn == mem (>= 0 only for the augmented operand) reads as 1, mn > mem as 0.
+__device__ __forceinline__ void fetch_mncont(const float* __restrict__ p, int ld, int mn0, int mem, bool aug,
+                                             int k0, int kend, bool vec_ok, float (&v)[4]) {
+    const int t = threadIdx.x;
+    const int k = k0 + (t >> 4);
+    const int mn = mn0 + (t & 15) * 4;
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (k < kend) {
+        const float* q = p + (long long)k * ld + mn;
+        if (vec_ok && mn + 3 < mem) {
+            const float4 f = *reinterpret_cast<const float4*>(q);
+            v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (mn + c < mem) v[c] = q[c];
+                else if (aug && mn + c == mem) v[c] = 1.f;
+            }
+        }
+    }
+}
+__device__ __forceinline__ void store_mncont(float* s, const float (&v)[4]) {
+    const int t = threadIdx.x;
+    *reinterpret_cast<float4*>(&s[(t >> 4) * LDS_STRIDE + (t & 15) * 4]) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+template <bool A_KCONT, bool B_KCONT, int EPI>
+__global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[BK * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LDS_STRIDE];
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int kbeg = 0, kend = g.K;
+    if (EPI == EPI_DW) {
+        kbeg = blockIdx.z * g.k_per_split;
+        kend = min(g.K, kbeg + g.k_per_split);
+    }
+    const bool a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) &&
+                       (A_KCONT ? (kbeg % 4 == 0) : true);
+    const bool b_vec = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0) &&
+                       (B_KCONT ? (kbeg % 4 == 0) : true);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {
+        if (A_KCONT) fetch_kcont(g.A, g.lda, m0, g.M, k0, kend, a_vec, ra);
+        else fetch_mncont(g.A, g.lda, m0, g.a_mem, EPI == EPI_DW, k0, kend, a_vec, ra);
+        if (B_KCONT) fetch_kcont(g.B, g.ldb, n0, g.N, k0, kend, b_vec, rb);
+        else fetch_mncont(g.B, g.ldb, n0, g.N, false, k0, kend, b_vec, rb);
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        __syncthreads();                       // previous tile fully consumed
+        if (A_KCONT) store_kcont(As, ra); else store_mncont(As, ra);
+        if (B_KCONT) store_kcont(Bs, rb); else store_mncont(Bs, rb);
+        __syncthreads();
+        if (k0 + BK < kend) fetch(k0 + BK);    // in flight under the MFMAs below
+        const float* pa = As + (lane >> 5) * LDS_STRIDE + wm * 32 + (lane & 31);
+        const float* pb = Bs + (lane >> 5) * LDS_STRIDE + wn * 32 + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk * LDS_STRIDE], pb[kk * LDS_STRIDE], acc, 0, 0, 0);
+        }
+    }
+    // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col >= g.N) return;
+    float bias = 0.f, sdev = 0.f;
+    if (EPI == EPI_FWD || EPI == EPI_REPARAM) bias = g.bias ? g.bias[col] : 0.f;
+    if (EPI == EPI_REPARAM) sdev = __expf(0.5f * g.lv[col]);
+    float* C = g.C;
+    if (EPI == EPI_DW) C += (long long)blockIdx.z * g.slab_stride;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= g.M) continue;
+        const long long o = (long long)row * g.ldc + col;
+        float v = acc[r];
+        if (EPI == EPI_FWD) {
+            v += bias;
+            if (g.relu) v = fmaxf(v, 0.f);
+            C[o] = v;
+        } else if (EPI == EPI_REPARAM) {
+            v += bias;
+            C[o] = v;
+            g.C2[o] = v + sdev * g.aux[o];
+        } else if (EPI == EPI_DX) {
+            if (g.relu) v = g.aux[o] > 0.f ? v : 0.f;
+            if (g.accumulate) v += C[o];
+            C[o] = v;
+        } else {
+            C[o] = v;
+        }
+    }
+}
+
+template <bool A_KCONT, bool B_KCONT, int EPI>
+static int launch(const GemmArgs& g, int splits, hipStream_t st) {
+    if (g.M <= 0 || g.N <= 0) return VAEK_OK;
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
+    if (grid.y > 65535u || grid.z > 65535u) {
+        set_error("gemm grid too large (M=%d N=%d splits=%d)", g.M, g.N, splits);
+        return VAEK_ERR_INVALID;
+    }
+    hipLaunchKernelGGL((gemm_f32_kernel<A_KCONT, B_KCONT, EPI>), grid, dim3(NT), 0, st, g);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+int launch_dense_fwd(const float* x, const float* w, const float* b, float* y, int rows, int n_in,
+                     int n_out, bool relu, hipStream_t st) {
+    GemmArgs g{};
+    g.A = x; g.B = w; g.C = y; g.M = rows; g.N = n_out; g.K = n_in;
+    g.lda = n_in; g.ldb = n_out; g.ldc = n_out; g.a_mem = 0; g.bias = b; g.relu = relu;
+    return launch<true, false, EPI_FWD>(g, 1, st);
+}
+
+int launch_dense_fwd_reparam(const float* x, const float* w, const float* b, float* mu, float* samples,
+                             const float* z1, const float* lv, int rows, int n_in, int n_out, hipStream_t st) {
+    GemmArgs g{};
+    g.A = x; g.B = w; g.C = mu; g.C2 = samples; g.aux = z1; g.lv = lv;
+    g.M = rows; g.N = n_out; g.K = n_in; g.lda = n_in; g.ldb = n_out; g.ldc = n_out; g.bias = b;
+    return launch<true, false, EPI_REPARAM>(g, 1, st);
+}
+
+int launch_dense_bwd_dx(const float* dy, const float* w, const float* x_post, float* dx, int rows,
+                        int n_in, int n_out, bool relu, bool accumulate, hipStream_t st) {
+    // dX[rows, n_in] = dY[rows, n_out] . W^T ; B(k = out index, j = in index) = W[j*n_out + k]
+    GemmArgs g{};
+    g.A = dy; g.B = w; g.C = dx; g.M = rows; g.N = n_in; g.K = n_out;
+    g.lda = n_out; g.ldb = n_out; g.ldc = n_in; g.aux = x_post; g.relu = relu && x_post != nullptr;
+    g.accumulate = accumulate;
+    return launch<true, true, EPI_DX>(g, 1, st);
+}
+
+int launch_dense_bwd_dw(const float* x, const float* dy, float* slab0, int64_t slab_stride, int S,
+                        int rows_per_split, int rows, int n_in, int n_out, hipStream_t st) {
+    // G[(n_in+1), n_out] = [X | 1]^T . dY, reduction over the batch rows of this split
+    GemmArgs g{};
+    g.A = x; g.B = dy; g.C = slab0; g.M = n_in + 1; g.N = n_out; g.K = rows;
+    g.lda = n_in; g.ldb = n_out; g.ldc = n_out; g.a_mem = n_in;
+    g.k_per_split = rows_per_split; g.slab_stride = slab_stride;
+    return launch<false, false, EPI_DW>(g, S, st);
+}
+
+}  // namespace vaek

@@ -1,0 +1,133 @@
+// Internal declarations shared by the translation units of libvaek.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/vaek.h"
+
+namespace vaek {
+
+constexpr int kExtra = 4;          // grads[P..P+3] = loss, mean Dkl, mean mse, 0
+constexpr float kLog2Pi = 1.8378770664093453f;
+constexpr float kAdamB1 = 0.9f, kAdamB2 = 0.999f, kAdamEps = 1e-8f;
+
+void set_error(const char* fmt, ...);
+#define VAEK_HIP_CHECK(expr)                                                              \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            vaek::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return VAEK_ERR_HIP;                                                          \
+        }                                                                                 \
+    } while (0)
+
+struct Leaf {
+    std::string name;
+    int64_t offset;
+    int rows, cols;   // bias / epsilon_p / epsilon: rows == 1
+};
+
+struct Layer {
+    int n_in, n_out;
+    int64_t w_off;    // kernel offset in the flat buffers; bias follows at w_off + n_in*n_out
+    bool relu;        // relu after this layer (every layer but the last, networks.py:35-39)
+};
+
+struct Net {
+    std::vector<Layer> layers;
+    // workspace byte offsets of each layer's OUTPUT activation [B, n_out] (float32)
+    std::vector<size_t> act_off;
+};
+
+struct Comm {
+    bool ready = false;
+    void* local = nullptr;
+    std::vector<void*> peers;   // world entries; peers[rank] == local
+    uint32_t epoch = 0;
+};
+
+}  // namespace vaek
+
+struct vaek_ctx {
+    vaek_config cfg;
+    int B, D, L;
+    int64_t Bt;                      // global batch (divisor of the mean)
+    int64_t P;                       // trainable floats
+    std::vector<vaek::Leaf> leaves;
+    vaek::Net enc, dec, sig;         // sig empty unless cfg.sigmoid_decoder
+    int64_t off_epsp, off_eps;       // flat offsets; off_eps = -1 without -tdv
+    // batch split of the deterministic reductions: S slabs for the dW|db GEMMs, Se for elementwise
+    int S, rows_per_split, Se, rows_per_esplit;
+    bool fused;                      // fused small-model path available and selected
+    // workspace layout (bytes)
+    size_t ws_samples, ws_dsamp, ws_gbuf0, ws_gbuf1, ws_slabs, ws_epart, ws_rpart, ws_fused, ws_total;
+    int max_width;
+    int n_cu;
+    vaek::Comm comm;
+};
+
+namespace vaek {
+
+// ---- gemm_f32.hip -------------------------------------------------------------------------
+int launch_dense_fwd(const float* x, const float* w, const float* b, float* y, int rows, int n_in,
+                     int n_out, bool relu, hipStream_t st);
+// y = mu (stored), samples = mu + exp(lv/2) * z1
+int launch_dense_fwd_reparam(const float* x, const float* w, const float* b, float* mu, float* samples,
+                             const float* z1, const float* lv, int rows, int n_in, int n_out, hipStream_t st);
+int launch_dense_bwd_dx(const float* dy, const float* w, const float* x_post, float* dx, int rows,
+                        int n_in, int n_out, bool relu, bool accumulate, hipStream_t st);
+// writes S slabs: slab[s][row*n_out + col], row in [0, n_in] (row n_in = bias), stride in floats
+int launch_dense_bwd_dw(const float* x, const float* dy, float* slab0, int64_t slab_stride, int S,
+                        int rows_per_split, int rows, int n_in, int n_out, hipStream_t st);
+
+// ---- elbo.hip -----------------------------------------------------------------------------
+struct ElboArgs {
+    const float* x; const float* y_lin; const float* y_sig; const float* z2; const float* mu;
+    const float* eps_param;   // device (1,) or nullptr
+    float eps_cli;            // eps = eps_param ? *eps_param * eps_cli : eps_cli
+    float* d_lin; float* d_sig;   // nullptr -> no gradients (eval)
+    float* partial;           // [S][4]: +0 = sum mse terms (variable part), +1 = sum mu^2, +2 = d eps sum (variable part)
+    int rows, D, L, S, rows_per_split;
+    float inv_bt;
+    int32_t* step_dev;        // incremented by block 0 (may be nullptr)
+};
+int launch_elbo(const ElboArgs& a, hipStream_t st);
+// dmu = dsamp + mu * inv_bt (in place on dsamp); partial[s][l] = sum_rows dsamp * z1
+int launch_reparam_bwd(float* dsamp, const float* mu, const float* z1, float* partial,
+                       int rows, int L, int S, int rows_per_split, float inv_bt, hipStream_t st);
+struct FinalizeArgs {
+    const float* slabs; int64_t slab_stride; int S;   // dW|db partials in flat-gradient layout
+    const float* epart; const float* rpart; int Se;   // elbo partials [Se][4], reparam partials [Se][L]
+    int64_t P, off_epsp, off_eps; int L, D;
+    const float* params;      // for logvar_e / epsilon
+    float eps_cli; float rows_over_bt; float inv_bt; float rows;
+    float* grads;             // P + 4
+    // optional fused Adam (world == 1): params_rw != nullptr
+    float* params_rw; float* m; float* v; const int32_t* step_dev; float lr;
+};
+int launch_finalize(const FinalizeArgs& a, hipStream_t st);
+int launch_adam(float* params, const float* grads, float* m, float* v, int64_t n, float lr, int step,
+                const int32_t* step_dev, float grad_scale, hipStream_t st);
+// x_hat = y_lin (+ sigmoid(y_sig)) + z2 * exp(eps/2)
+int launch_add_noise(const float* y_lin, const float* y_sig, const float* z2, const float* eps_param,
+                     float eps_cli, float* x_hat, int64_t n, hipStream_t st);
+// stand-alone ELBO finalisation for vaek_elbo_fwd_bwd: out4 = {loss, dkl, mse, d eps}
+int launch_elbo_out4(const float* partial, int S, const float* lv, int L, int D,
+                     float eps, float rows, float inv_bt, float* out4, hipStream_t st);
+// eval: out4 = {loss, dkl, mse, eps} from slabs
+int launch_eval_out4(const float* partial, int S, const float* params, int64_t off_epsp,
+                     int64_t off_eps, int L, int D, float eps_cli, float rows, float inv_bt, float* out4,
+                     hipStream_t st);
+int launch_sum_slabs(const float* slabs, int64_t stride, int S, float* out, int64_t n, hipStream_t st);
+
+// ---- fused_small.hip ----------------------------------------------------------------------
+bool fused_supported(const vaek_ctx* c);
+size_t fused_workspace_bytes(const vaek_ctx* c);
+int fused_train_step(vaek_ctx* c, float* params, float* grads, float* m, float* v, int32_t* step_dev,
+                     const float* x, const float* z1, const float* z2, float lr, bool apply_adam,
+                     void* ws, hipStream_t st);
+
+}  // namespace vaek

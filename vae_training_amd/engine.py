@@ -1,0 +1,182 @@
+"""Host-side handle on a libvaek context: flat parameter layout, workspace, raw kernel calls.
+
+Everything here passes raw device pointers of PyTorch-ROCm tensors plus torch's current HIP
+stream through the C ABI (include/vaek.h); torch is plumbing (memory, streams), not compute.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "libvaek takes contiguous device tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t, device):
+    if not torch.is_tensor(t):
+        t = torch.as_tensor(t)
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class Engine:
+    """One libvaek context = one (batch, architecture) shape on one GPU."""
+
+    def __init__(self, batch, data_dim, latent_dim, enc_hidden=(), dec_hidden=(), epsilon=0.0,
+                 tunable_decoder_var=False, sigmoid_decoder=False, device=None, world=1, rank=0,
+                 global_batch=0, dtype="f32", force_generic=False):
+        if not torch.cuda.is_available():
+            raise RuntimeError("vae_training_amd needs an MI355X (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        cfg = _lib.VaekConfig()
+        cfg.struct_size = C.sizeof(_lib.VaekConfig)
+        cfg.batch, cfg.data_dim, cfg.latent_dim = int(batch), int(data_dim), int(latent_dim)
+        enc_hidden, dec_hidden = list(enc_hidden), list(dec_hidden)
+        if len(enc_hidden) > _lib.VAEK_MAX_HIDDEN or len(dec_hidden) > _lib.VAEK_MAX_HIDDEN:
+            raise ValueError(f"at most {_lib.VAEK_MAX_HIDDEN} hidden layers per network")
+        cfg.n_enc_hidden, cfg.n_dec_hidden = len(enc_hidden), len(dec_hidden)
+        for i, h in enumerate(enc_hidden):
+            cfg.enc_hidden[i] = int(h)
+        for i, h in enumerate(dec_hidden):
+            cfg.dec_hidden[i] = int(h)
+        cfg.sigmoid_decoder = int(bool(sigmoid_decoder))
+        cfg.tunable_eps = int(bool(tunable_decoder_var))
+        cfg.eps_cli = float(epsilon)
+        cfg.dtype = {"f32": _lib.VAEK_F32, "bf16": _lib.VAEK_BF16}[dtype]
+        cfg.device = self.device.index
+        cfg.world, cfg.rank, cfg.global_batch = int(world), int(rank), int(global_batch)
+        cfg.force_generic = int(bool(force_generic))
+        self.cfg = cfg
+        h = C.c_void_p()
+        _lib.check(self.lib.vaek_ctx_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        n = C.c_int64()
+        _lib.check(self.lib.vaek_param_count(h, C.byref(n)))
+        self.P = n.value
+        _lib.check(self.lib.vaek_grad_len(h, C.byref(n)))
+        self.grad_len = n.value
+        nl = C.c_int32()
+        _lib.check(self.lib.vaek_leaf_count(h, C.byref(nl)))
+        self.leaves = OrderedDict()
+        buf = C.create_string_buffer(64)
+        for i in range(nl.value):
+            off, r, c = C.c_int64(), C.c_int32(), C.c_int32()
+            _lib.check(self.lib.vaek_leaf_info(h, i, buf, 64, C.byref(off), C.byref(r), C.byref(c)))
+            name = buf.value.decode()
+            shape = (c.value,) if r.value == 1 and not name.endswith("kernel") else (r.value, c.value)
+            self.leaves[name] = (off.value, shape)
+        ws = C.c_size_t()
+        _lib.check(self.lib.vaek_workspace_bytes(h, C.byref(ws)))
+        self.workspace = torch.empty(max(ws.value, 256), dtype=torch.uint8, device=self.device)
+        assert self.workspace.data_ptr() % 256 == 0
+        f = C.c_int32()
+        _lib.check(self.lib.vaek_uses_fused_path(h, C.byref(f)))
+        self.fused = bool(f.value)
+        self.batch, self.D, self.L = int(batch), int(data_dim), int(latent_dim)
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            try:
+                self.lib.vaek_ctx_destroy(h)
+            except Exception:
+                pass
+
+    # ---- flat buffers ----------------------------------------------------------------------
+    def new_flat(self, n=None):
+        return torch.zeros(self.P if n is None else n, dtype=torch.float32, device=self.device)
+
+    def views(self, flat):
+        """Nested dict of views into a flat buffer, reference param-tree names (vae.py:73-80)."""
+        tree = OrderedDict()
+        for name, (off, shape) in self.leaves.items():
+            numel = 1
+            for s in shape:
+                numel *= s
+            v = flat[off:off + numel].view(*shape)
+            node = tree
+            parts = name.split("/")
+            for p in parts[:-1]:
+                node = node.setdefault(p, OrderedDict())
+            node[parts[-1]] = v
+        return tree
+
+    # ---- hot path ----------------------------------------------------------------------------
+    def train_step(self, params, grads, m, v, step_dev, x, z1, z2, lr):
+        _lib.check(self.lib.vaek_train_step(self.h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(step_dev),
+                                            _ptr(x), _ptr(z1), _ptr(z2), float(lr), _ptr(self.workspace), _stream()))
+
+    def grads_only(self, params, grads, step_dev, x, z1, z2):
+        _lib.check(self.lib.vaek_train_step_grads_only(self.h, _ptr(params), _ptr(grads), _ptr(step_dev), _ptr(x),
+                                                       _ptr(z1), _ptr(z2), _ptr(self.workspace), _stream()))
+
+    def apply(self, params, grads, m, v, step_dev, lr):
+        _lib.check(self.lib.vaek_train_step_apply(self.h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v),
+                                                  _ptr(step_dev), float(lr), _stream()))
+
+    def loss_eval(self, params, x, z1, z2):
+        out = torch.empty(4, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.vaek_loss_eval(self.h, _ptr(params), _ptr(x), _ptr(z1), _ptr(z2), _ptr(out),
+                                           _ptr(self.workspace), _stream()))
+        return out
+
+    def forward(self, params, x, z1, z2, sampling=False, eps=0.0, want_mu=True):
+        rows = z1.shape[0]
+        x_hat = torch.empty(rows, self.D, dtype=torch.float32, device=self.device)
+        mu = torch.empty(rows, self.L, dtype=torch.float32, device=self.device) if want_mu else None
+        _lib.check(self.lib.vaek_forward(self.h, _ptr(params), _ptr(x), _ptr(z1), _ptr(z2), int(bool(sampling)),
+                                         float(eps), _ptr(x_hat), _ptr(mu), rows, _ptr(self.workspace), _stream()))
+        return x_hat, mu
+
+    # ---- building blocks -----------------------------------------------------------------------
+    def dense_fwd(self, x, w, b, relu=False):
+        rows, n_in = x.shape
+        n_out = w.shape[1]
+        y = torch.empty(rows, n_out, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.vaek_dense_fwd(self.h, _ptr(x), _ptr(w), _ptr(b), _ptr(y), rows, n_in, n_out,
+                                           int(relu), _stream()))
+        return y
+
+    def dense_bwd_dx(self, dy, w, x_post=None, relu=False, out=None, accumulate=False):
+        rows, n_out = dy.shape
+        n_in = w.shape[0]
+        dx = torch.empty(rows, n_in, dtype=torch.float32, device=self.device) if out is None else out
+        _lib.check(self.lib.vaek_dense_bwd_dx(self.h, _ptr(dy), _ptr(w), _ptr(x_post), _ptr(dx), rows, n_in, n_out,
+                                              int(relu), int(accumulate), _stream()))
+        return dx
+
+    def dense_bwd_dw(self, x, dy):
+        rows, n_in = x.shape
+        n_out = dy.shape[1]
+        dwb = torch.empty(n_in + 1, n_out, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.vaek_dense_bwd_dw(self.h, _ptr(x), _ptr(dy), _ptr(dwb), rows, n_in, n_out,
+                                              _ptr(self.workspace), _stream()))
+        return dwb
+
+    def elbo_fwd_bwd(self, x, x_hat_lin, x_hat_sig, z2, mu, logvar_e, eps, batch_total=0, grads=True):
+        rows, D = x.shape
+        L = mu.shape[1]
+        out4 = torch.empty(4, dtype=torch.float32, device=self.device)
+        d_lin = torch.empty_like(x_hat_lin) if grads else None
+        d_sig = torch.empty_like(x_hat_sig) if (grads and x_hat_sig is not None) else None
+        _lib.check(self.lib.vaek_elbo_fwd_bwd(self.h, _ptr(x), _ptr(x_hat_lin), _ptr(x_hat_sig), _ptr(z2), _ptr(mu),
+                                              _ptr(logvar_e), float(eps), _ptr(d_lin), _ptr(d_sig), _ptr(out4),
+                                              rows, D, L, int(batch_total), _ptr(self.workspace), _stream()))
+        return out4, d_lin, d_sig
+
+    def adam_step(self, params, grads, m, v, lr, step=None, step_dev=None, grad_scale=1.0):
+        _lib.check(self.lib.vaek_adam_step(self.h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(),
+                                           float(lr), int(step or 0), _ptr(step_dev), float(grad_scale), _stream()))
