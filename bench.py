@@ -1,0 +1,304 @@
+#!/usr/bin/env python3
+"""bench.py -- ELBO train-step samples/sec (BASELINE.json metric) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one VAE.train_step (networks.py:87-101: forward, ELBO, backward, Adam) over one batch of
+synthetic linear-padding data already resident in HBM.  Default workload "M" = the configuration
+the metric is quoted on: linear_gaussian dd=3 pad=9 (D=12), latent 20, linear encoder/decoder,
+-tdv, epsilon=-1, lr=1e-3 (seed_linpadding_expts.sh:1) at batch 65 536 PER GPU (weak scaling;
+--scaling strong divides a global 65 536 over the ranks instead).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # name: (dataset, dd, did, pad, D, L, enc_hidden, dec_hidden, eps, tdv, lr, default batch)
+    "M": dict(dataset="linear_gaussian", dd=3, did=3, pad=9, L=20, enc=(), dec=(), eps=-1.0, tdv=True, lr=1e-3, batch=65536,
+              desc="linear-padding dd3 pad9 (D=12) L=20 linear enc/dec -tdv eps=-1 lr=1e-3 (seed_linpadding_expts.sh:1)"),
+    "M20": dict(dataset="linear_gaussian", dd=3, did=3, pad=17, L=20, enc=(), dec=(), eps=-1.0, tdv=True, lr=1e-3, batch=65536,
+                desc="linear-padding dd3 pad17 (D=20) L=20 linear (seed_linpadding_expts.sh:2)"),
+    "C2": dict(dataset="sigmoid", dd=3, did=3, pad=3, L=6, enc=(256,), dec=(256,), eps=-3.0, tdv=True, lr=1e-4, batch=8192,
+               desc="sigmoid dd3 pad3 (D=7) L=6 width-256 MLP, two decoders"),
+    "C3": dict(dataset="sphere", dd=3, did=3, pad=3, L=6, enc=(512, 512, 512), dec=(512, 512, 512), eps=-3.0, tdv=True,
+               lr=1e-4, batch=65536, desc="sphere dd3 pad3 (D=6) L=6 512|512|512 MLP"),
+    "C4": dict(dataset="linear_gaussian", dd=3, did=3, pad=4093, L=20, enc=(), dec=(), eps=-1.0, tdv=True, lr=1e-3,
+               batch=32768, desc="linear-padding ambient D=4096 L=20 linear"),
+}
+
+
+def data_dim(w):
+    return w["dd"] + w["pad"] + (1 if w["dataset"] == "sigmoid" else 0)
+
+
+def n_params(w):
+    D, L = data_dim(w), w["L"]
+    def net(k, hs, last):
+        n = 0
+        for h in list(hs) + [last]:
+            n += k * h + h
+            k = h
+        return n
+    P = net(D, w["enc"], L) + net(L, w["dec"], D) * (2 if w["dataset"] == "sigmoid" else 1) + L + (1 if w["tdv"] else 0)
+    return P
+
+
+def flops_per_sample(w):
+    D, L = data_dim(w), w["L"]
+    def pw(k, hs, last):
+        n, first = 0, None
+        for h in list(hs) + [last]:
+            if first is None:
+                first = k * h
+            n += k * h
+            k = h
+        return n, first
+    e, e1 = pw(D, w["enc"], L)
+    d, _ = pw(L, w["dec"], D)
+    nd = 2 if w["dataset"] == "sigmoid" else 1
+    return 2 * (e + nd * d) * 2 + 2 * (e - e1 + nd * d)     # fwd + dW + dX (no dX for the encoder input)
+
+
+def init_params_flat(eng, seed=0):
+    """lecun-normal kernels (truncated normal / sqrt(fan_in)), zero biases, epsilon_p = epsilon = 1."""
+    g = torch.Generator().manual_seed(seed)
+    flat = torch.zeros(eng.P, dtype=torch.float32)
+    for name, (off, shape) in eng.leaves.items():
+        n = int(np.prod(shape))
+        if name.endswith("kernel"):
+            w = torch.empty(shape, dtype=torch.float32)
+            torch.nn.init.trunc_normal_(w, mean=0.0, std=1.0, a=-2.0, b=2.0, generator=g)
+            flat[off:off + n] = (w * (math.sqrt(1.0 / shape[0]) / 0.87962566103423978)).reshape(-1)
+        elif name.startswith("epsilon"):
+            flat[off:off + n] = 1.0
+    return flat.to(eng.device)
+
+
+def make_batches(w, B, device, nbuf, seed):
+    """Synthetic inputs restating datasets.py (linear :183-195, sigmoid :240-249, sphere :75-84) plus
+    z ~ N(0,1)^(L+D) (model.py:227), generated on the device; `nbuf` rotating batches."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    gc = torch.Generator().manual_seed(2)                   # dataset seed (-ds 2)
+    D, L, dd = data_dim(w), w["L"], w["dd"]
+    A = torch.randn(dd, w["did"] if w["dataset"] == "linear_gaussian" else 1, generator=gc).to(device)
+    out = []
+    for _ in range(nbuf):
+        x = torch.zeros(B, D, dtype=torch.float32, device=device)
+        if w["dataset"] == "linear_gaussian":
+            x[:, :dd] = torch.randn(B, w["did"], device=device, generator=g) @ A.T
+        elif w["dataset"] == "sigmoid":
+            z = torch.randn(B, dd, device=device, generator=g)
+            x[:, :dd] = z
+            x[:, dd] = torch.sigmoid(z @ A).squeeze(1)
+        else:
+            s = torch.randn(B, dd, device=device, generator=g)
+            x[:, :dd] = s / s.norm(dim=1, keepdim=True)
+        z = torch.randn(B, L + D, device=device, generator=g)
+        out.append((x.contiguous(), z[:, :L].contiguous(), z[:, L:].contiguous()))
+    return out
+
+
+def cpu_baseline(w, B, seconds):
+    """The torch float32 restatement (oracle/elbo_torch.py) of the same train step on the host
+    cores: "CPU restatement (torch), not JAX" (BASELINE.md section 3).  Checker code, timed only here."""
+    from oracle import elbo_oracle as O
+    from oracle import elbo_torch as T
+    cfg = O.Config(data_dim(w), w["L"], w["enc"], w["dec"], w["eps"], w["tdv"], w["dataset"])
+    threads = torch.get_num_threads()
+    p = O.init_params(cfg, seed=0)
+    model = T.TorchVAE(cfg, p, dtype=torch.float32)
+    opt = T.make_adam(model, w["lr"])
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, cfg.D, generator=g); z1 = torch.randn(B, cfg.L, generator=g); z2 = torch.randn(B, cfg.D, generator=g)
+    for _ in range(2):
+        T.train_step(model, opt, x, z1, z2)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        T.train_step(model, opt, x, z1, z2)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 2000:
+            break
+    return {"value": B * n / dt, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"{n} train steps at batch {B} of the same workload, torch-CPU float32 restatement "
+                      f"(oracle/elbo_torch.py), {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="M", choices=list(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (weak) / global batch (strong); 0 = workload default")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--comm", default="auto", choices=["auto", "rccl", "p2p"])
+    ap.add_argument("--nbuf", type=int, default=4, help="rotating synthetic input batches resident in HBM")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--force-generic", action="store_true", help="layer-by-layer kernels even where a fused path exists")
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="steps captured per hipGraph (0 = eager launches; -1 = auto: nbuf-multiple near 20, single GPU only)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no MI355X visible; the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from vae_training_amd.engine import Engine
+    from vae_training_amd.parallel import GradExchange
+
+    w = WORKLOADS[args.workload]
+    B0 = args.batch or w["batch"]
+    if args.scaling == "weak":
+        B_local, B_global = B0, B0 * world
+    else:
+        assert B0 % world == 0, "strong scaling needs batch divisible by the rank count"
+        B_local, B_global = B0 // world, B0
+    D, L = data_dim(w), w["L"]
+    eng = Engine(B_local, D, L, w["enc"], w["dec"], w["eps"], w["tdv"], w["dataset"] == "sigmoid", device=local_rank,
+                 world=world, rank=rank, global_batch=B_global, force_generic=args.force_generic)
+    params = init_params_flat(eng, seed=0)
+    grads = eng.new_flat(eng.grad_len)
+    m, v = eng.new_flat(), eng.new_flat()
+    step_dev = torch.zeros(1, dtype=torch.int32, device=device)
+    batches = make_batches(w, B_local, device, args.nbuf, seed=1000 + rank)
+    exch = GradExchange(eng, dist, mode=args.comm) if world > 1 else None
+    lr = w["lr"]
+
+    def one_step(i):
+        x, z1, z2 = batches[i % len(batches)]
+        if exch is None or exch.in_library:
+            eng.train_step(params, grads, m, v, step_dev, x, z1, z2, lr)
+        else:
+            eng.grads_only(params, grads, step_dev, x, z1, z2)
+            exch.all_reduce(grads)
+            eng.apply(params, grads, m, v, step_dev, lr)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # The steady-state loop is launch-bound (two ~5-10 us kernels per step), so G consecutive steps
+    # are captured once into a hipGraph and replayed; every step inside still runs the full forward,
+    # backward and Adam on its own (rotating) batch, and K timed steps are exactly K train steps.
+    gsteps = args.graph
+    if gsteps < 0:
+        gsteps = 0 if exch is not None and not exch.in_library else max(len(batches), 20 // len(batches) * len(batches))
+    graph = None
+    n_warm_eager = max(args.warmup, 3)
+    for i in range(n_warm_eager):
+        one_step(i)
+    if gsteps > 0:
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                for i in range(gsteps):
+                    one_step(i)
+        torch.cuda.current_stream().wait_stream(side)
+        graph.replay()                      # one untimed replay (graph upload)
+
+    def run_steps(n):
+        done = 0
+        if graph is not None:
+            while n - done >= gsteps:
+                graph.replay()
+                done += gsteps
+        for i in range(n - done):
+            one_step(i)
+
+    fence()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(grads[eng.P].item())
+    assert math.isfinite(loss), "train step produced a non-finite loss"
+
+    # ---- roofline leg: the same K steps again with every library launch bracketed by hipEvents ----
+    roofline = None
+    if not args.no_roofline:
+        eng.profile_begin(max_records=args.steps * 64)
+        for i in range(args.steps):
+            one_step(i)
+        torch.cuda.synchronize()
+        rep = eng.profile_report()
+        if rep:
+            dom = max(rep, key=lambda k: rep[k]["total_ms"])
+            avg_s = rep[dom]["total_ms"] / rep[dom]["count"] * 1e-3
+            P = eng.P
+            if flops_per_sample(w) / (4.0 * (2 * D + L)) > 300.0:   # above the f32/bf16 ridge: MFMA-bound (C3)
+                alg = B_local * flops_per_sample(w)
+                peak, unit, bound = 157.3, "TFLOP/s", "mfma"
+                achieved = alg / avg_s / 1e12
+            else:
+                alg = B_local * 4 * (2 * D + L)
+                peak, unit, bound = 8000.0, "GB/s", "hbm"
+                achieved = alg / avg_s / 1e9
+            roofline = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
+                        "traffic": None, "kernel": dom, "kernel_avg_us": avg_s * 1e6,
+                        "launches_per_step": rep[dom]["count"] / args.steps,
+                        "algorithmic_per_launch": alg,
+                        "step_kernels_us": {k: r["total_ms"] / args.steps * 1e3 for k, r in rep.items()},
+                        "param_bytes_per_step": 32 * P}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(w, B_local, args.cpu_seconds)
+
+    if rank == 0:
+        value = B_global * args.steps / elapsed
+        out = {
+            "metric": "ELBO train-step samples/sec", "value": value, "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {w['desc']}", "batch_per_gpu": B_local, "global_batch": B_global,
+                       "data_dim": D, "latent_dim": L, "params": eng.P, "path": "fused" if eng.fused else "layer-by-layer",
+                       "parallelism": f"dp{world}", "grad_exchange": (exch.mode if exch else "none"),
+                       "launch": (f"hipGraph x{gsteps} steps" if graph is not None else "eager"),
+                       "final_loss": loss},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

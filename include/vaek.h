@@ -167,6 +167,14 @@ int vaek_comm_destroy(vaek_ctx* ctx);
 /* Stand-alone sum all-reduce of n floats in place through the communicator (n <= grad_len). */
 int vaek_comm_allreduce(vaek_ctx* ctx, float* buf, int64_t n, void* stream);
 
+/* ---- in-process kernel timing (bench.py's roofline leg) --------------------------------------- */
+/* Between begin and report every kernel the library launches for this context is bracketed by a
+ * pair of hipEvents recorded on the launch stream (pool of max_records pairs, allocated here, so
+ * the launch path still allocates nothing).  vaek_profile_report synchronises the events, stops
+ * profiling and writes a JSON object {"label": {"count": n, "total_ms": t}, ...} into buf. */
+int vaek_profile_begin(vaek_ctx* ctx, int32_t max_records);
+int vaek_profile_report(vaek_ctx* ctx, char* buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

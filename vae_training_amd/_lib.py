@@ -57,6 +57,8 @@ SIGNATURES = {
     "vaek_comm_init": (C.c_int, [_vp, _vp, _vp]),
     "vaek_comm_destroy": (C.c_int, [_vp]),
     "vaek_comm_allreduce": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "vaek_profile_begin": (C.c_int, [_vp, _i32]),
+    "vaek_profile_report": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
 }
 
 _lib = None
@@ -71,6 +73,9 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `make -C {os.path.dirname(LIB_PATH)}` or "
             "`python -c 'import __graft_entry__ as g; g.build()'`. vae_training_amd has no CPU/PyTorch fallback.")
+    # torch first: libvaek shares device pointers and streams with PyTorch-ROCm, so both must use
+    # the one HIP runtime torch ships (same SONAME libamdhip64.so.7 -- whoever loads first wins)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

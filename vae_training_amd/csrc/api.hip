@@ -12,6 +12,11 @@
 namespace vaek {
 
 static thread_local char g_err[512] = "";
+thread_local Profiler* g_prof = nullptr;
+struct ProfBind {   // entry points bind the context's profiler for the duration of the call
+    explicit ProfBind(vaek_ctx* c) { g_prof = c ? &c->prof : nullptr; }
+    ~ProfBind() { g_prof = nullptr; }
+};
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -178,7 +183,7 @@ int vaek_ctx_create(const vaek_config* cfg, vaek_ctx** out) {
         if (cfg->enc_hidden[i] <= 0) { set_error("encoder hidden width %d <= 0", cfg->enc_hidden[i]); return VAEK_ERR_INVALID; }
     for (int i = 0; i < cfg->n_dec_hidden; ++i)
         if (cfg->dec_hidden[i] <= 0) { set_error("decoder hidden width %d <= 0", cfg->dec_hidden[i]); return VAEK_ERR_INVALID; }
-    if (cfg->latent_dim > 256) { set_error("latent_dim %d > 256 unsupported", cfg->latent_dim); return VAEK_ERR_INVALID; }
+    if (cfg->latent_dim > 250) { set_error("latent_dim %d > 250 unsupported", cfg->latent_dim); return VAEK_ERR_INVALID; }
     if (cfg->dtype != VAEK_F32 && cfg->dtype != VAEK_BF16) { set_error("unknown dtype %d", cfg->dtype); return VAEK_ERR_INVALID; }
 
     int ndev = 0;
@@ -248,6 +253,7 @@ int vaek_ctx_create(const vaek_config* cfg, vaek_ctx** out) {
 int vaek_ctx_destroy(vaek_ctx* ctx) {
     if (!ctx) return VAEK_OK;
     vaek_comm_destroy(ctx);
+    for (auto e : ctx->prof.ev) (void)hipEventDestroy(e);
     delete ctx;
     return VAEK_OK;
 }
@@ -367,6 +373,7 @@ int vaek_adam_step(vaek_ctx* ctx, float* params, const float* grads, float* m, f
 // ---- the hot path ----------------------------------------------------------------------------
 int vaek_train_step_grads_only(vaek_ctx* ctx, const float* params, float* grads, int32_t* step_dev, const float* x,
                                const float* z1, const float* z2, void* workspace, void* stream) {
+    ProfBind pb(ctx);
     if (!ctx || !params || !grads || !step_dev || !x || !z1 || !z2) { set_error("vaek_train_step_grads_only: null argument"); return VAEK_ERR_INVALID; }
     int rc = check_ws(ctx, workspace);
     if (rc) return rc;
@@ -380,12 +387,14 @@ int vaek_train_step_grads_only(vaek_ctx* ctx, const float* params, float* grads,
 
 int vaek_train_step_apply(vaek_ctx* ctx, float* params, const float* grads, float* m, float* v,
                           const int32_t* step_dev, float lr, void* stream) {
+    ProfBind pb(ctx);
     if (!ctx || !params || !grads || !m || !v || !step_dev) { set_error("vaek_train_step_apply: null argument"); return VAEK_ERR_INVALID; }
     return launch_adam(params, grads, m, v, ctx->P, lr, 0, step_dev, 1.f, (hipStream_t)stream);
 }
 
 int vaek_train_step(vaek_ctx* ctx, float* params, float* grads, float* m, float* v, int32_t* step_dev, const float* x,
                     const float* z1, const float* z2, float lr, void* workspace, void* stream) {
+    ProfBind pb(ctx);
     if (!ctx || !params || !grads || !m || !v || !step_dev || !x || !z1 || !z2) { set_error("vaek_train_step: null argument"); return VAEK_ERR_INVALID; }
     int rc = check_ws(ctx, workspace);
     if (rc) return rc;
@@ -407,6 +416,7 @@ int vaek_train_step(vaek_ctx* ctx, float* params, float* grads, float* m, float*
 
 int vaek_loss_eval(vaek_ctx* ctx, const float* params, const float* x, const float* z1, const float* z2, float* out4,
                    void* workspace, void* stream) {
+    ProfBind pb(ctx);
     if (!ctx || !params || !x || !z1 || !z2 || !out4) { set_error("vaek_loss_eval: null argument"); return VAEK_ERR_INVALID; }
     int rc = check_ws(ctx, workspace);
     if (rc) return rc;
@@ -432,6 +442,7 @@ int vaek_loss_eval(vaek_ctx* ctx, const float* params, const float* x, const flo
 
 int vaek_forward(vaek_ctx* ctx, const float* params, const float* x, const float* z1, const float* z2,
                  int32_t sampling, float eps, float* x_hat, float* mu_out, int32_t rows, void* workspace, void* stream) {
+    ProfBind pb(ctx);
     if (!ctx || !params || !z1 || !z2 || !x_hat || (!sampling && !x) || rows <= 0) { set_error("vaek_forward: invalid argument"); return VAEK_ERR_INVALID; }
     if (rows > ctx->B) { set_error("vaek_forward: rows %d exceed this context's batch %d", rows, ctx->B); return VAEK_ERR_WORKSPACE; }
     int rc = check_ws(ctx, workspace);
@@ -456,6 +467,56 @@ int vaek_forward(vaek_ctx* ctx, const float* params, const float* x, const float
     return launch_add_noise(at<float>(workspace, c->dec.act_off.back()),
                             sig ? at<float>(workspace, c->sig.act_off.back()) : nullptr, z2, eps_param, eps_val, x_hat,
                             (int64_t)rows * c->D, st);
+}
+
+// Diagnostic hook (not part of include/vaek.h): device buffer for the in-kernel s_memtime stamps of
+// a -DVAEK_STAMPS build (tools/stamps.sh).  No effect in the shipped build.
+int vaek_debug_set_stamps(vaek_ctx* ctx, unsigned long long* buf) {
+    if (!ctx) return VAEK_ERR_INVALID;
+    ctx->dbg_stamps = buf;
+    return VAEK_OK;
+}
+
+int vaek_profile_begin(vaek_ctx* ctx, int32_t max_records) {
+    if (!ctx || max_records <= 0) { set_error("vaek_profile_begin: invalid argument"); return VAEK_ERR_INVALID; }
+    Profiler& p = ctx->prof;
+    while ((int)p.ev.size() < 2 * max_records) {
+        hipEvent_t e;
+        VAEK_HIP_CHECK(hipEventCreate(&e));
+        p.ev.push_back(e);
+    }
+    p.label.assign(max_records, nullptr);
+    p.cap = max_records; p.n = 0; p.on = true;
+    return VAEK_OK;
+}
+
+int vaek_profile_report(vaek_ctx* ctx, char* buf, size_t cap) {
+    if (!ctx || !buf || cap < 8) { set_error("vaek_profile_report: invalid argument"); return VAEK_ERR_INVALID; }
+    Profiler& p = ctx->prof;
+    p.on = false;
+    std::vector<std::string> names;
+    std::vector<double> total;
+    std::vector<int> count;
+    for (int i = 0; i < p.n; ++i) {
+        VAEK_HIP_CHECK(hipEventSynchronize(p.ev[2 * i + 1]));
+        float ms = 0.f;
+        VAEK_HIP_CHECK(hipEventElapsedTime(&ms, p.ev[2 * i], p.ev[2 * i + 1]));
+        size_t k = 0;
+        for (; k < names.size(); ++k) if (names[k] == p.label[i]) break;
+        if (k == names.size()) { names.push_back(p.label[i]); total.push_back(0); count.push_back(0); }
+        total[k] += ms; count[k] += 1;
+    }
+    std::string js = "{";
+    for (size_t k = 0; k < names.size(); ++k) {
+        char tmp[160];
+        snprintf(tmp, sizeof(tmp), "%s\"%s\": {\"count\": %d, \"total_ms\": %.6f}", k ? ", " : "", names[k].c_str(), count[k], total[k]);
+        js += tmp;
+    }
+    js += "}";
+    if (js.size() + 1 > cap) { set_error("vaek_profile_report: buffer too small"); return VAEK_ERR_INVALID; }
+    memcpy(buf, js.c_str(), js.size() + 1);
+    p.n = 0;
+    return VAEK_OK;
 }
 
 }  // extern "C"

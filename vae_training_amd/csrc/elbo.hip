@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256) void elbo_kernel(const ElboArgs a) {
 
 int launch_elbo(const ElboArgs& a, hipStream_t st) {
     const bool sig = a.y_sig != nullptr, grads = a.d_lin != nullptr;
+    ProfScope ps("elbo", st);
     dim3 grid(a.S), block(256);
     if (sig && grads) hipLaunchKernelGGL((elbo_kernel<true, true>), grid, block, 0, st, a);
     else if (sig) hipLaunchKernelGGL((elbo_kernel<true, false>), grid, block, 0, st, a);
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256) void reparam_bwd_kernel(float* dsamp, const fl
 int launch_reparam_bwd(float* dsamp, const float* mu, const float* z1, float* partial,
                        int rows, int L, int S, int rows_per_split, float inv_bt, hipStream_t st) {
     if (L > 256) { set_error("latent_dim %d > 256 not supported by reparam_bwd", L); return VAEK_ERR_INVALID; }
+    ProfScope ps("reparam_bwd", st);
     hipLaunchKernelGGL(reparam_bwd_kernel, dim3(S), dim3(256), 256 * sizeof(float), st, dsamp, mu, z1, partial,
                        rows, L, rows_per_split, inv_bt);
     VAEK_HIP_CHECK(hipGetLastError());
@@ -133,17 +135,29 @@ __device__ __forceinline__ void adam_bias_corrections(int t, float& bc1, float& 
     bc2 = -expm1f((float)t * -0.0010005003335835335f);
 }
 
+// Block b covers outputs [n - 256(b+1), n - 256b): epsilon_p, epsilon and the scalar sums (which
+// need each other, and whose parameters the loss reads) always sit together in block 0, so the
+// barrier between "every read of params" and "first Adam write" is block-local.  L <= 250.
 __global__ __launch_bounds__(256) void finalize_kernel(const FinalizeArgs a) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float sh[3][256];
+    const int t = threadIdx.x;
     const long long n = a.P + kExtra;
-    if (i >= n) return;
+    const long long i = n - 256ll * ((long long)blockIdx.x + 1) + t;
+    if (blockIdx.x == 0) {      // fixed-order cooperative sum of the elbo partials [Se][4]
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+        for (int s = t; s < a.Se; s += 256) { m0 += a.epart[s * 4 + 0]; m1 += a.epart[s * 4 + 1]; m2 += a.epart[s * 4 + 2]; }
+        sh[0][t] = m0; sh[1][t] = m1; sh[2][t] = m2;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (t < w) { sh[0][t] += sh[0][t + w]; sh[1][t] += sh[1][t + w]; sh[2][t] += sh[2][t + w]; }
+            __syncthreads();
+        }
+    }
     float g = 0.f;
-    if (i < a.P) {
+    if (i >= 0 && i < a.P) {
         if (i == a.off_eps) {
-            float d = 0.f;
-            for (int s = 0; s < a.Se; ++s) d += a.epart[s * 4 + 2];
             // eps = param * eps_cli, networks.py:71; + 0.5 per (row, d) element is the constant part
-            g = a.eps_cli * (d + 0.5f * a.rows * (float)a.D) * a.inv_bt;
+            g = a.eps_cli * (sh[2][0] + 0.5f * a.rows * (float)a.D) * a.inv_bt;
         } else if (i >= a.off_epsp && i < a.off_epsp + a.L) {
             for (int s = 0; s < a.Se; ++s) g += a.rpart[(long long)s * a.L + (i - a.off_epsp)];
             const float lv = a.params[i];
@@ -151,19 +165,16 @@ __global__ __launch_bounds__(256) void finalize_kernel(const FinalizeArgs a) {
         } else {
             for (int s = 0; s < a.S; ++s) g += a.slabs[(long long)s * a.slab_stride + i];
         }
-    } else if (i == a.P || i == a.P + 1 || i == a.P + 2) {
-        float smse = 0.f, smusq = 0.f;
-        for (int s = 0; s < a.Se; ++s) {
-            smse += a.epart[s * 4 + 0];
-            smusq += a.epart[s * 4 + 1];
-        }
+    } else if (i >= a.P && i < a.P + 3) {
         float klc = 0.f;   // sum_l (1 + lv - e^lv)
         for (int l = 0; l < a.L; ++l) { const float lv = a.params[a.off_epsp + l]; klc += 1.f + lv - expf(lv); }
         const float eps = a.off_eps >= 0 ? a.params[a.off_eps] * a.eps_cli : a.eps_cli;
-        const float dkl = (0.5f * smusq - 0.5f * a.rows * klc) * a.inv_bt;
-        const float mse = (smse + 0.5f * a.rows * (float)a.D * (kLog2Pi + eps)) * a.inv_bt;
+        const float dkl = (0.5f * sh[1][0] - 0.5f * a.rows * klc) * a.inv_bt;
+        const float mse = (sh[0][0] + 0.5f * a.rows * (float)a.D * (kLog2Pi + eps)) * a.inv_bt;
         g = (i == a.P) ? dkl + mse : (i == a.P + 1 ? dkl : mse);
     }
+    __syncthreads();            // every read of params above precedes every Adam write below
+    if (i < 0) return;
     a.grads[i] = g;
     if (a.params_rw && i < a.P) {
         float bc1, bc2;
@@ -176,6 +187,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const FinalizeArgs a) {
 
 int launch_finalize(const FinalizeArgs& a, hipStream_t st) {
     const long long n = a.P + kExtra;
+    ProfScope ps(a.params_rw ? "finalize_adam" : "finalize", st);
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
@@ -197,6 +209,7 @@ int launch_adam(float* params, const float* grads, float* m, float* v, int64_t n
                 const int32_t* step_dev, float grad_scale, hipStream_t st) {
     if (n <= 0) return VAEK_OK;
     const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+    ProfScope ps("adam", st);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, params, grads, m, v, (long long)n, lr, step,
                        step_dev, grad_scale);
     VAEK_HIP_CHECK(hipGetLastError());

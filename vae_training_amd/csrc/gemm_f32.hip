@@ -131,7 +131,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
     if (col >= g.N) return;
     float bias = 0.f, sdev = 0.f;
     if (EPI == EPI_FWD || EPI == EPI_REPARAM) bias = g.bias ? g.bias[col] : 0.f;
-    if (EPI == EPI_REPARAM) sdev = __expf(0.5f * g.lv[col]);
+    if (EPI == EPI_REPARAM) sdev = expf(0.5f * g.lv[col]);
     float* C = g.C;
     if (EPI == EPI_DW) C += (long long)blockIdx.z * g.slab_stride;
 #pragma unroll
@@ -161,6 +161,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
 template <bool A_KCONT, bool B_KCONT, int EPI>
 static int launch(const GemmArgs& g, int splits, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return VAEK_OK;
+    ProfScope ps(EPI == EPI_FWD ? "gemm_f32_fwd" : EPI == EPI_REPARAM ? "gemm_f32_fwd_reparam"
+                 : EPI == EPI_DX ? "gemm_f32_dx" : "gemm_f32_dw", st);
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
     if (grid.y > 65535u || grid.z > 65535u) {
         set_error("gemm grid too large (M=%d N=%d splits=%d)", g.M, g.N, splits);

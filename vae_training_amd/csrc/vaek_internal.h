@@ -42,6 +42,27 @@ struct Net {
     std::vector<size_t> act_off;
 };
 
+// Event-pair pool for vaek_profile_*: one pair per kernel launch while enabled.
+struct Profiler {
+    bool on = false;
+    std::vector<hipEvent_t> ev;          // 2 * max_records
+    std::vector<const char*> label;      // per record
+    int n = 0, cap = 0;
+};
+extern thread_local Profiler* g_prof;    // set by the C entry points for the duration of a call
+struct ProfScope {                       // brackets one launch on `st`
+    hipStream_t st; int idx = -1;
+    ProfScope(const char* label, hipStream_t s) : st(s) {
+        Profiler* p = g_prof;
+        if (p && p->on && p->n < p->cap) {
+            idx = p->n++;
+            p->label[idx] = label;
+            (void)hipEventRecord(p->ev[2 * idx], st);
+        }
+    }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof->ev[2 * idx + 1], st); }
+};
+
 struct Comm {
     bool ready = false;
     void* local = nullptr;
@@ -67,6 +88,8 @@ struct vaek_ctx {
     int max_width;
     int n_cu;
     vaek::Comm comm;
+    vaek::Profiler prof;
+    unsigned long long* dbg_stamps = nullptr;   // diagnostic builds (-DVAEK_STAMPS) only
 };
 
 namespace vaek {

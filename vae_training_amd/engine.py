@@ -141,6 +141,16 @@ class Engine:
                                          float(eps), _ptr(x_hat), _ptr(mu), rows, _ptr(self.workspace), _stream()))
         return x_hat, mu
 
+    # ---- in-process kernel timing (bench.py) ------------------------------------------------
+    def profile_begin(self, max_records=4096):
+        _lib.check(self.lib.vaek_profile_begin(self.h, int(max_records)))
+
+    def profile_report(self):
+        import json
+        buf = C.create_string_buffer(8192)
+        _lib.check(self.lib.vaek_profile_report(self.h, buf, 8192))
+        return json.loads(buf.value.decode())
+
     # ---- building blocks -----------------------------------------------------------------------
     def dense_fwd(self, x, w, b, relu=False):
         rows, n_in = x.shape
