@@ -1,0 +1,150 @@
+"""CPU tests of the host side: CLI mirror, layout, param tree, checkpoints, datasets, RNG keys,
+the C-ABI surface (symbols only: no compute call without a GPU)."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import elbo_oracle as O
+from tests.cases import CASES, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cli_flags_and_defaults_match_reference():
+    """Every flag name and default of /root/reference/run.py:10-38."""
+    from vae_training_amd.run import parse_arguments
+    a = parse_arguments(["exp"])
+    want = dict(name="exp", num_batches=15000, num_epochs=10000, batch_size=100, learning_rate=0.0001, padding_dim=0,
+                overwrite=False, dataset="4gaussian", layer_sizes="512|512", encoder_layer_sizes="512|512",
+                latent_dimension=100, nojit=False, padding_type="none", dataset_seed=69, state_dict=None, data_fn=None,
+                warm_start=False, initialize_inverse=False, use_fred_covariance=False, epsilon=0.0,
+                tunable_decoder_var=False, dataset_noise=0.0, dataset_dimension=3, warm_start_linear=False,
+                dataset_intrinsic_dimension=3, latent_off_dimension=1, model="VAE", latent_distribution="gaussian", tqdm=True)
+    for k, v in want.items():
+        assert getattr(a, k) == v, k
+    # the first line of seed_linpadding_expts.sh parses to the metric's configuration
+    b = parse_arguments("vae3 --dataset linear_gaussian --encoder_layer_sizes  --layer_sizes  -ow --latent_dim 20 "
+                        "--padding_dim 9 -dd 3 --num_batches 100000 --epsilon -1 -tdv -ds 2 -lr 1e-3".replace("sizes  ", "sizes= ").split())
+    assert (b.dataset, b.latent_dimension, b.padding_dim, b.dataset_dimension, b.epsilon, b.tunable_decoder_var,
+            b.dataset_seed, b.learning_rate, b.overwrite) == ("linear_gaussian", 20, 9, 3, -1.0, True, 2, 1e-3, True)
+    with pytest.raises(SystemExit):
+        parse_arguments(["exp", "--dataset", "4gaussian"])      # not a valid choice in the reference either
+
+
+def test_layer_size_parsing():
+    from vae_training_amd.vae import parse_layer_sizes
+    assert parse_layer_sizes("") == [] and parse_layer_sizes("200|200|200") == [200, 200, 200] and parse_layer_sizes("7") == [7]
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_layout_matches_oracle_leaf_order(name):
+    from vae_training_amd import layout
+    cfg, _, _, _ = build(name)
+    lv, P = layout.leaves(cfg.D, cfg.L, cfg.enc_sizes[:-1], cfg.dec_sizes[:-1], cfg.sigmoid, cfg.tdv)
+    assert P == cfg.n_params()
+    off = 0
+    for (n, shape), (n2, (o, s)) in zip(cfg.leaves(), lv.items()):
+        assert n == n2 and tuple(shape) == tuple(s) and o == off
+        off += int(np.prod(shape))
+
+
+def test_make_output_dir(tmp_path, monkeypatch):
+    from vae_training_amd import utils
+    monkeypatch.setattr(utils, "DATA_DIR", str(tmp_path) + "/")
+    d = utils.make_output_dir("e1", False, {"a": 1})
+    assert json.load(open(os.path.join(d, "args.json"))) == {"a": 1}
+    open(os.path.join(d, "junk"), "w").write("x")
+    with pytest.raises(ValueError):
+        utils.make_output_dir("e1", False, {"a": 1})
+    utils.make_output_dir("e1", True, {"a": 2})
+    assert sorted(os.listdir(d)) == ["args.json"]
+
+
+def test_param_tree_init_and_checkpoint_roundtrip():
+    from vae_training_amd import random as vr
+    from vae_training_amd.networks import VAE, Model
+    from vae_training_amd.optim import Adam
+    mod = VAE.partial(epsilon=-3.0, encoder_layer_sizes=[64, 6], decoder_layer_sizes=[64, 7], tunable_decoder_var=True,
+                      dataset_name="sigmoid", device="cpu")
+    _, p = mod.init_by_shape(vr.PRNGKey(0), [(7,), (6,), (7,)])
+    assert list(p) == ["Encoder", "Decoder", "SigDecoder", "epsilon_p", "epsilon"]
+    assert p["Encoder"]["FC0"]["kernel"].shape == (7, 64) and p["Decoder"]["FC1"]["bias"].shape == (7,)
+    w = p["Decoder"]["FC0"]["kernel"]
+    assert float(w.abs().max()) <= 2.0 * np.sqrt(1 / 6) / 0.87962566103423978 + 1e-6      # truncated at 2 sigma
+    assert abs(float(p["Encoder"]["FC1"]["kernel"].std()) - np.sqrt(1 / 64)) < 0.03        # lecun normal
+    assert float(p["epsilon_p"].sum()) == 6.0 and float(p["epsilon"][0]) == 1.0 and float(p["Encoder"]["FC0"]["bias"].abs().sum()) == 0
+    model = Model(mod, p)
+    assert model.flat.numel() == O.Config(7, 6, (64,), (64,), -3.0, True, "sigmoid").n_params()
+    model.params["epsilon_p"].fill_(0.5)                 # views alias the flat buffer
+    assert float(model.flat[mod.leaves["epsilon_p"][0]]) == 0.5
+    opt = Adam(learning_rate=1e-3).create(model)
+    opt.state.m.uniform_(); opt.state.v.uniform_(); opt.state.step = 7
+    sd = opt.state_dict()
+    assert sd["state"]["step"] == 7 and set(sd["target"]["params"]) == set(p)
+    assert sd["state"]["param_states"]["Encoder"]["FC0"]["kernel"]["grad_ema"].shape == (7, 64)
+    model2 = Model(mod, mod.init_by_shape(vr.PRNGKey(1), [(7,), (6,), (7,)])[1])
+    opt2 = Adam(learning_rate=1e-3).create(model2).load_state_dict(sd)
+    assert torch.equal(opt2.target.flat, model.flat) and torch.equal(opt2.state.m, opt.state.m) and opt2.state.step == 7
+    with pytest.raises(RuntimeError):                    # compute has no CPU fallback
+        model(torch.zeros(4, 7), torch.zeros(4, 6), torch.zeros(4, 7))
+
+
+def test_random_keys():
+    from vae_training_amd import random as vr
+    k = vr.PRNGKey(0)
+    a, b = vr.split(k)
+    assert a != b and vr.split(k) == (a, b) and vr.split(vr.PRNGKey(1)) != (a, b)
+    x = vr.normal(a, (1000, 8), "cpu")
+    assert torch.equal(x, vr.normal(a, (1000, 8), "cpu")) and abs(float(x.mean())) < 0.05 and abs(float(x.std()) - 1) < 0.05
+
+
+def test_datasets_restatement():
+    from vae_training_amd.datasets import LinearGaussianDataset, SigmoidDataset, SphereDataset
+    lg = LinearGaussianDataset(2, dimension=3, intrinsic_dimension=3, padding_dimension=9, device="cpu")
+    x = lg.get_batch(2000)
+    assert x.shape == (2000, 12) and lg.shape == (12,) and lg.dimension == 12 and not lg.is_epochs
+    assert float(x[:, 3:].abs().max()) == 0.0
+    cov = np.cov(x[:, :3].numpy().T)
+    assert np.allclose(cov, lg.transformed_cov.numpy(), atol=0.25 * np.abs(lg.transformed_cov.numpy()).max())
+    assert lg.get_batch(4, return_latents=True)[1] is None
+    assert float(LinearGaussianDataset(2, 3, 3, 9, var_added=0.01, device="cpu").get_batch(500)[:, 3:].std()) == pytest.approx(0.1, rel=0.1)
+    sg = SigmoidDataset(69, dimension=3, padding_dimension=3, device="cpu")
+    y = sg.get_batch(100)
+    assert y.shape == (100, 7) and torch.allclose(y[:, 3], torch.sigmoid(y[:, :3] @ sg.A).squeeze(1)) and float(y[:, 4:].abs().max()) == 0
+    sp = SphereDataset(69, dimension=3, padding_dimension=3, device="cpu")
+    s = sp.get_batch(100)
+    assert torch.allclose(s[:, :3].norm(dim=1), torch.ones(100), atol=1e-5) and float(s[:, 3:].abs().max()) == 0
+    assert set(sp.score_batch(s)) == {"Sphere Error", "Padding Error"}
+    assert set(lg.score_batch(x)) == {"Squared Norm of padding dimensions"}
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """include/vaek.h <-> libvaek.so <-> the ctypes table: identical symbol sets (no compute calls here)."""
+    from vae_training_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "vaek.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(vaek_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.vaek_version() == 100
+    if not torch.cuda.is_available():
+        import ctypes as C
+        cfg = _lib.VaekConfig(); cfg.struct_size = C.sizeof(cfg); cfg.batch = 8; cfg.data_dim = 4; cfg.latent_dim = 2; cfg.world = 1
+        h = C.c_void_p()
+        assert lib.vaek_ctx_create(C.byref(cfg), C.byref(h)) == -3           # VAEK_ERR_NO_DEVICE: fails loudly
+        assert b"no HIP device" in lib.vaek_last_error()
+        cfg.struct_size = 12
+        assert lib.vaek_ctx_create(C.byref(cfg), C.byref(h)) == -1           # ABI guard
+
+
+def test_engine_refuses_to_run_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from vae_training_amd.engine import Engine
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Engine(8, 4, 2)

@@ -420,6 +420,17 @@ __global__ __launch_bounds__(1024) void fused_finalize_kernel(const FusedFinArgs
     const int n = a.P + kExtra;
     const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int idx = n - 64 * ((int)blockIdx.x + 1) + o;
+    // Adam state of this output is fetched NOW, under the partial-row loads, not after the reduction
+    const bool adam = a.params_rw != nullptr && q == 0 && idx >= 0 && idx < a.P;
+    float p_old = 0.f, m_old = 0.f, v_old = 0.f;
+    int tstep = 0;
+    if (adam) { p_old = a.params_rw[idx]; m_old = a.m[idx]; v_old = a.v[idx]; tstep = a.step_dev[0]; }
+    // closed-form KL pieces: each epsilon_p lane contributes its own 1 + lv - e^lv (block 0 holds them all)
+    __shared__ float klt[64];
+    const bool is_lv = q == 0 && idx >= a.off_epsp && idx < a.off_epsp + a.L;
+    const float lv_own = is_lv ? a.params[idx] : 0.f;
+    const float eps_par = (q == 0 && blockIdx.x == 0 && a.off_eps >= 0) ? a.params[a.off_eps] : 0.f;
+    if (q == 0) klt[o] = is_lv ? 1.f + lv_own - expf(lv_own) : 0.f;
     float acc = 0.f;
     if (idx >= 0) {
         const float* p = a.partials + idx;
@@ -448,15 +459,15 @@ __global__ __launch_bounds__(1024) void fused_finalize_kernel(const FusedFinArgs
     const int base = n - 64 * ((int)blockIdx.x + 1);          // index of sums[0]
     if (!live) {
     } else if (idx >= a.off_epsp && idx < a.off_epsp + a.L) {
-        const float lv = a.params[idx];
+        const float lv = lv_own;
         g = 0.5f * expf(0.5f * lv) * g - 0.5f * (1.f - expf(lv)) * a.rows_over_bt;
     } else if (idx == a.off_eps) {
         g = a.eps_cli * (sums[a.P + 2 - base] + 0.5f * a.rows * (float)a.D) * a.inv_bt;
     } else if (idx >= a.P) {
         if (idx < a.P + 3) {
             float klc = 0.f;
-            for (int l = 0; l < a.L; ++l) { const float lv = a.params[a.off_epsp + l]; klc += 1.f + lv - expf(lv); }
-            const float eps = a.off_eps >= 0 ? a.params[a.off_eps] * a.eps_cli : a.eps_cli;
+            for (int l = 0; l < a.L; ++l) klc += klt[a.off_epsp - base + l];
+            const float eps = a.off_eps >= 0 ? eps_par * a.eps_cli : a.eps_cli;
             const float dkl = (0.5f * sums[a.P + 1 - base] - 0.5f * a.rows * klc) * a.inv_bt;
             const float mse = (sums[a.P - base] + 0.5f * a.rows * (float)a.D * (kLog2Pi + eps)) * a.inv_bt;
             g = idx == a.P ? dkl + mse : (idx == a.P + 1 ? dkl : mse);
@@ -467,13 +478,11 @@ __global__ __launch_bounds__(1024) void fused_finalize_kernel(const FusedFinArgs
     __syncthreads();            // every read of params above precedes every Adam write below
     if (!live) return;
     a.grads[idx] = g;
-    if (a.params_rw && idx < a.P) {
-        const int tstep = a.step_dev[0];
+    if (adam) {
         const float bc1 = -expm1f((float)tstep * -0.10536051565782628f);
         const float bc2 = -expm1f((float)tstep * -0.0010005003335835335f);
-        float p = a.params_rw[idx], mm = a.m[idx], vv = a.v[idx];
-        adam_apply_f(p, g, mm, vv, a.lr, bc1, bc2);
-        a.params_rw[idx] = p; a.m[idx] = mm; a.v[idx] = vv;
+        adam_apply_f(p_old, g, m_old, v_old, a.lr, bc1, bc2);
+        a.params_rw[idx] = p_old; a.m[idx] = m_old; a.v[idx] = v_old;
     }
 }
 

@@ -10,7 +10,7 @@ from collections import OrderedDict
 
 import torch
 
-from . import _lib
+from . import _lib, layout
 
 
 def _ptr(t):
@@ -78,6 +78,8 @@ class Engine:
             name = buf.value.decode()
             shape = (c.value,) if r.value == 1 and not name.endswith("kernel") else (r.value, c.value)
             self.leaves[name] = (off.value, shape)
+        want, want_p = layout.leaves(data_dim, latent_dim, enc_hidden, dec_hidden, sigmoid_decoder, tunable_decoder_var)
+        assert want_p == self.P and list(want.items()) == list(self.leaves.items()), "layout.py disagrees with libvaek"
         ws = C.c_size_t()
         _lib.check(self.lib.vaek_workspace_bytes(h, C.byref(ws)))
         self.workspace = torch.empty(max(ws.value, 256), dtype=torch.uint8, device=self.device)
@@ -100,19 +102,7 @@ class Engine:
         return torch.zeros(self.P if n is None else n, dtype=torch.float32, device=self.device)
 
     def views(self, flat):
-        """Nested dict of views into a flat buffer, reference param-tree names (vae.py:73-80)."""
-        tree = OrderedDict()
-        for name, (off, shape) in self.leaves.items():
-            numel = 1
-            for s in shape:
-                numel *= s
-            v = flat[off:off + numel].view(*shape)
-            node = tree
-            parts = name.split("/")
-            for p in parts[:-1]:
-                node = node.setdefault(p, OrderedDict())
-            node[parts[-1]] = v
-        return tree
+        return layout.views(flat, self.leaves)
 
     # ---- hot path ----------------------------------------------------------------------------
     def train_step(self, params, grads, m, v, step_dev, x, z1, z2, lr):
