@@ -248,6 +248,8 @@ def main():
         elapsed = float(t.item())
     loss = float(grads[eng.P].item())
     assert math.isfinite(loss), "train step produced a non-finite loss"
+    if exch is not None and exch.in_library:
+        assert not exch.timed_out(), "p2p gradient exchange gave up waiting for a peer"
 
     # ---- roofline leg: the same K steps again with every library launch bracketed by hipEvents ----
     roofline = None

@@ -154,18 +154,21 @@ int vaek_forward(vaek_ctx* ctx, const float* params, const float* x, const float
                  void* workspace, void* stream);
 
 /* ---- data-parallel exchange over xGMI (one-shot peer-to-peer all-reduce of the flat grads) -- */
-/* Every rank allocates nothing itself: it passes a caller-owned device buffer `comm_buf` of
- * vaek_comm_buffer_bytes() bytes (hipMalloc'ed, zero-filled), exports it with
- * vaek_comm_export, exchanges the 64-byte handles out of band (torch.distributed all_gather)
- * and opens all of them with vaek_comm_init.  After that vaek_train_step sums gradients over
- * ranks inside its finalize kernel.  Without a communicator and world > 1, use
- * vaek_train_step_grads_only + an RCCL all-reduce + vaek_train_step_apply. */
+/* The reference is single-device; this is the build's data-parallel addition.
+ * Every rank calls vaek_comm_create (allocates ITS uncached exchange buffer -- the one allocation the
+ * library makes after ctx_create -- and exports a 64-byte HIP IPC handle), the handles are
+ * exchanged out of band (torch.distributed all_gather), and vaek_comm_init maps all peers.  After
+ * that vaek_train_step sums gradients over ranks INSIDE its finalize kernel (tagged 8-byte granules
+ * stored straight into every peer's buffer over xGMI; bounded spins).  Without a communicator and
+ * world > 1 use vaek_train_step_grads_only + an RCCL all-reduce + vaek_train_step_apply. */
 int vaek_comm_buffer_bytes(const vaek_ctx* ctx, size_t* bytes);
-int vaek_comm_export(vaek_ctx* ctx, void* comm_buf, uint8_t handle_out[64]);
-int vaek_comm_init(vaek_ctx* ctx, void* comm_buf, const uint8_t* all_handles /* world x 64 */);
+int vaek_comm_create(vaek_ctx* ctx, uint8_t handle_out[64]);
+int vaek_comm_init(vaek_ctx* ctx, const uint8_t* all_handles /* world x 64 */);
 int vaek_comm_destroy(vaek_ctx* ctx);
 /* Stand-alone sum all-reduce of n floats in place through the communicator (n <= grad_len). */
 int vaek_comm_allreduce(vaek_ctx* ctx, float* buf, int64_t n, void* stream);
+/* Synchronous: *timed_out = 1 if any exchange on this rank ever gave up waiting for a peer. */
+int vaek_comm_status(vaek_ctx* ctx, int32_t* timed_out);
 
 /* ---- in-process kernel timing (bench.py's roofline leg) --------------------------------------- */
 /* Between begin and report every kernel the library launches for this context is bracketed by a

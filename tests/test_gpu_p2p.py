@@ -1,0 +1,79 @@
+"""-m gpu: the library's peer-to-peer gradient exchange, rehearsed with W ranks sharing ONE GPU
+(HIP IPC between processes, tagged granules, both banks, epochs = Adam steps).  Cross-device
+coherence over xGMI cannot be exercised on a one-GPU box; the protocol, the IPC plumbing, the
+in-finalize fusion and replica bit-identity can."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import elbo_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        from vae_training_amd.engine import Engine
+        from vae_training_amd.parallel import GradExchange, shard_rows
+        cfg = O.Config(12, 20, (), (), -1.0, True, "linear_gaussian")
+        B, lr, steps = 1024, 1e-3, 4
+        rng = np.random.default_rng(0)
+        r32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+        p = {k: r32(v) for k, v in O.init_params(cfg, seed=0).items()}
+        xs = [r32(rng.standard_normal((B, 12))) for _ in range(steps)]
+        zs = [r32(rng.standard_normal((B, 32))) for _ in range(steps)]
+        lo, hi = shard_rows(B, world, rank)
+        eng = Engine(hi - lo, 12, 20, (), (), -1.0, True, False, world=world, rank=rank, global_batch=B)
+        assert eng.fused
+        ex = GradExchange(eng, dist, mode="p2p")
+        assert ex.in_library and ex.mode == "p2p"
+        dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda()
+        params = dev(O.flatten(cfg, p)); grads = eng.new_flat(eng.grad_len); m = eng.new_flat(); v = eng.new_flat()
+        step = torch.zeros(1, dtype=torch.int32, device="cuda")
+        st = O.adam_init(p)
+        worst = 0.0
+        for s in range(steps):
+            z1, z2 = O.split_latents(zs[s], 20)
+            p, st, loss_ref = O.train_step(cfg, p, st, xs[s], z1, z2, lr)          # full batch on the oracle
+            eng.train_step(params, grads, m, v, step, dev(xs[s][lo:hi]), dev(z1[lo:hi]), dev(z2[lo:hi]), lr)
+            torch.cuda.synchronize()
+            worst = max(worst, abs(float(grads[eng.P]) - loss_ref) / abs(loss_ref))
+        perr = float(np.max(np.abs(params.cpu().numpy().astype(np.float64) - O.flatten(cfg, p))))
+        digest = torch.tensor(params.cpu().numpy().view(np.int32).astype(np.int64).sum().reshape(1))
+        allg = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(allg, digest)
+        q.put((rank, worst, perr, all(int(a) == int(allg[0]) for a in allg), ex.timed_out(), None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:            # report instead of hanging the parent
+        import traceback
+        q.put((rank, 1.0, 1.0, False, True, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_p2p_exchange_inside_finalize(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, lerr, perr, same, timed_out, tb in res:
+        assert tb is None, tb
+        assert lerr <= 1e-5 and perr <= 0.02 * 1e-3 and same and not timed_out, (rank, lerr, perr, same, timed_out)

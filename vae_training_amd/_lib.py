@@ -53,8 +53,9 @@ SIGNATURES = {
     "vaek_loss_eval": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vaek_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _i32, _vp, _vp]),
     "vaek_comm_buffer_bytes": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
-    "vaek_comm_export": (C.c_int, [_vp, _vp, _vp]),
-    "vaek_comm_init": (C.c_int, [_vp, _vp, _vp]),
+    "vaek_comm_create": (C.c_int, [_vp, _vp]),
+    "vaek_comm_init": (C.c_int, [_vp, _vp]),
+    "vaek_comm_status": (C.c_int, [_vp, C.POINTER(_i32)]),
     "vaek_comm_destroy": (C.c_int, [_vp]),
     "vaek_comm_allreduce": (C.c_int, [_vp, _vp, _i64, _vp]),
     "vaek_profile_begin": (C.c_int, [_vp, _i32]),

@@ -380,7 +380,7 @@ int vaek_train_step_grads_only(vaek_ctx* ctx, const float* params, float* grads,
     hipStream_t st = (hipStream_t)stream;
     if (ctx->fused)
         return fused_train_step(ctx, const_cast<float*>(params), grads, nullptr, nullptr, step_dev, x, z1, z2, 0.f, false,
-                                workspace, st);
+                                false, workspace, st);
     if ((rc = generic_grads(ctx, params, step_dev, x, z1, z2, workspace, st))) return rc;
     return generic_finalize(ctx, params, grads, nullptr, nullptr, nullptr, nullptr, 0.f, workspace, st);
 }
@@ -405,11 +405,13 @@ int vaek_train_step(vaek_ctx* ctx, float* params, float* grads, float* m, float*
                       "vaek_train_step_grads_only + all-reduce + vaek_train_step_apply", ctx->cfg.world);
             return VAEK_ERR_COMM;
         }
+        // fused path: the exchange happens inside the finalize kernel (the step stays two launches)
+        if (ctx->fused) return fused_train_step(ctx, params, grads, m, v, step_dev, x, z1, z2, lr, true, true, workspace, st);
         if ((rc = vaek_train_step_grads_only(ctx, params, grads, step_dev, x, z1, z2, workspace, stream))) return rc;
         if ((rc = vaek_comm_allreduce(ctx, grads, ctx->P + kExtra, stream))) return rc;
         return vaek_train_step_apply(ctx, params, grads, m, v, step_dev, lr, stream);
     }
-    if (ctx->fused) return fused_train_step(ctx, params, grads, m, v, step_dev, x, z1, z2, lr, true, workspace, st);
+    if (ctx->fused) return fused_train_step(ctx, params, grads, m, v, step_dev, x, z1, z2, lr, true, false, workspace, st);
     if ((rc = generic_grads(ctx, params, step_dev, x, z1, z2, workspace, st))) return rc;
     return generic_finalize(ctx, params, grads, params, m, v, step_dev, lr, workspace, st);
 }

@@ -17,6 +17,7 @@
 //       Each workgroup emits ONE partial gradient row; no float atomics anywhere.
 //   fused_finalize_kernel fixed-order sum of the partial rows, the closed-form KL / log-variance
 //       terms, loss/Dkl/mse means, and Adam (flax.optim.Adam.apply_gradient, networks.py:100).
+#include "comm_dev.h"
 #include "vaek_internal.h"
 
 namespace vaek {
@@ -402,6 +403,7 @@ struct FusedFinArgs {
     const float* params; float eps_cli, rows_over_bt, inv_bt, rows;
     float* grads;
     float* params_rw; float* m; float* v; const int32_t* step_dev; float lr;
+    CommDev comm;              // comm.world > 1: sum over ranks inside this kernel (epoch = Adam step)
 };
 
 __device__ __forceinline__ void adam_apply_f(float& p, float g, float& m, float& v, float lr, float bc1, float bc2) {
@@ -477,6 +479,7 @@ __global__ __launch_bounds__(1024) void fused_finalize_kernel(const FusedFinArgs
     }
     __syncthreads();            // every read of params above precedes every Adam write below
     if (!live) return;
+    if (a.comm.world > 1) g = comm_exchange_sum(a.comm, (unsigned)a.step_dev[0], idx, g);   // xGMI, all ranks
     a.grads[idx] = g;
     if (adam) {
         const float bc1 = -expm1f((float)tstep * -0.10536051565782628f);
@@ -535,7 +538,7 @@ size_t fused_workspace_bytes(const vaek_ctx* c) {
 }
 
 int fused_train_step(vaek_ctx* c, float* params, float* grads, float* m, float* v, int32_t* step_dev,
-                     const float* x, const float* z1, const float* z2, float lr, bool apply_adam,
+                     const float* x, const float* z1, const float* z2, float lr, bool apply_adam, bool exchange,
                      void* ws, hipStream_t st) {
     const FusedVariant* var = pick_variant(c);
     if (!var) { set_error("fused path not available for this configuration"); return VAEK_ERR_INVALID; }
@@ -570,6 +573,8 @@ int fused_train_step(vaek_ctx* c, float* params, float* grads, float* m, float* 
     f.rows_over_bt = (float)((double)c->B / (double)c->Bt); f.inv_bt = a.inv_bt; f.rows = (float)c->B;
     f.grads = grads;
     f.params_rw = apply_adam ? params : nullptr; f.m = m; f.v = v; f.step_dev = step_dev; f.lr = lr;
+    f.comm = CommDev{};
+    if (exchange) f.comm = comm_dev(c, 0);
     {
         ProfScope ps(apply_adam ? "fused_finalize_adam" : "fused_finalize", st);
         hipLaunchKernelGGL(fused_finalize_kernel, dim3((unsigned)((c->P + kExtra + 63) / 64)), dim3(1024), 0, st, f);

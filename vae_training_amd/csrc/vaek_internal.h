@@ -65,9 +65,11 @@ struct ProfScope {                       // brackets one launch on `st`
 
 struct Comm {
     bool ready = false;
-    void* local = nullptr;
-    std::vector<void*> peers;   // world entries; peers[rank] == local
-    uint32_t epoch = 0;
+    void* local = nullptr;      // uncached granule buffer of this rank (hipExtMallocWithFlags)
+    size_t bytes = 0;
+    int ng = 0;                 // granules per (bank, source rank)
+    std::vector<void*> peers;   // world entries; peers[rank] == local, others IPC-mapped
+    uint32_t epoch = 0;         // stand-alone all-reduce epochs (region 1)
 };
 
 }  // namespace vaek
@@ -146,11 +148,15 @@ int launch_eval_out4(const float* partial, int S, const float* params, int64_t o
                      hipStream_t st);
 int launch_sum_slabs(const float* slabs, int64_t stride, int S, float* out, int64_t n, hipStream_t st);
 
+// ---- comm.hip -------------------------------------------------------------------------------
+struct CommDev;
+CommDev comm_dev(const vaek_ctx* c, int region);
+
 // ---- fused_small.hip ----------------------------------------------------------------------
 bool fused_supported(const vaek_ctx* c);
 size_t fused_workspace_bytes(const vaek_ctx* c);
 int fused_train_step(vaek_ctx* c, float* params, float* grads, float* m, float* v, int32_t* step_dev,
-                     const float* x, const float* z1, const float* z2, float lr, bool apply_adam,
+                     const float* x, const float* z1, const float* z2, float lr, bool apply_adam, bool exchange,
                      void* ws, hipStream_t st);
 
 }  // namespace vaek

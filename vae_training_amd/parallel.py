@@ -30,42 +30,77 @@ def shard_rows(n_rows: int, world: int, rank: int):
     return rank * per, (rank + 1) * per
 
 
+P2P_MAX_FLOATS = 1 << 16      # above this the exchange is bandwidth-, not latency-bound: RCCL's job
+
+
 class GradExchange:
     def __init__(self, engine, dist, mode="auto"):
         self.engine, self.dist = engine, dist
         self.world = dist.get_world_size() if dist is not None else 1
         self.in_library = False
-        if mode in ("auto", "p2p") and engine is not None and self.world > 1:
+        self.p2p_error = None
+        want_p2p = mode == "p2p" or (mode == "auto" and engine is not None and engine.grad_len <= P2P_MAX_FLOATS)
+        if want_p2p and engine is not None and self.world > 1:
+            ok = False
             try:
                 self._init_p2p()
-                self.in_library = True
+                ok = self._selftest()
             except Exception as e:                      # p2p is an optimisation; RCCL is always correct
+                self.p2p_error = str(e)
+            # every rank must take the same decision
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self._coll_device())
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                self.in_library = True
+            else:
+                _lib.check(engine.lib.vaek_comm_destroy(engine.h))
                 if mode == "p2p":
-                    raise
-                self._p2p_error = str(e)
+                    raise RuntimeError(f"p2p gradient exchange unavailable: {self.p2p_error or 'self-test failed on some rank'}")
         self.mode = "p2p" if self.in_library else "rccl"
+
+    def _coll_device(self):
+        return torch.device("cpu") if self.dist.get_backend() == "gloo" else self.engine.device
 
     def _init_p2p(self):
         eng, dist = self.engine, self.dist
         lib = eng.lib
-        n = C.c_size_t()
-        _lib.check(lib.vaek_comm_buffer_bytes(eng.h, C.byref(n)))
-        if n.value == 0:
-            raise RuntimeError("library built without the p2p communicator")
-        # a dedicated hipMalloc allocation (torch's caching allocator sub-allocates; IPC needs the base)
-        self.comm_buf = torch.zeros(n.value, dtype=torch.uint8, device=eng.device)
         handle = (C.c_uint8 * 64)()
-        _lib.check(lib.vaek_comm_export(eng.h, C.c_void_p(self.comm_buf.data_ptr()), handle))
-        mine = torch.tensor(list(handle), dtype=torch.uint8, device=eng.device)
+        _lib.check(lib.vaek_comm_create(eng.h, handle))
+        mine = torch.tensor(list(handle), dtype=torch.uint8, device=self._coll_device())
         allh = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(allh, mine)
         flat = torch.cat(allh).cpu().numpy().tobytes()
         buf = (C.c_uint8 * len(flat)).from_buffer_copy(flat)
-        _lib.check(lib.vaek_comm_init(eng.h, C.c_void_p(self.comm_buf.data_ptr()), buf))
+        _lib.check(lib.vaek_comm_init(eng.h, buf))
         dist.barrier()
 
+    def _selftest(self):
+        """Three stand-alone all-reduces (both granule banks) of rank-dependent values against the sum
+        formed locally in the same rank order; exact equality and no spin give-up required."""
+        eng = self.engine
+        n = min(eng.grad_len, 4096)
+        idx = torch.arange(n, dtype=torch.float32, device=eng.device)
+        for rnd in range(3):
+            contrib = lambda r: (idx * 0.001 + (r + 1) * (rnd + 1)).to(torch.float32)
+            buf = contrib(eng.cfg.rank).contiguous()
+            want = torch.zeros(n, dtype=torch.float32, device=eng.device)
+            for r in range(self.world):
+                want = want + contrib(r)
+            _lib.check(eng.lib.vaek_comm_allreduce(eng.h, C.c_void_p(buf.data_ptr()), n,
+                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            torch.cuda.synchronize()
+            if not torch.equal(buf, want):
+                self.p2p_error = f"self-test round {rnd}: wrong sum"
+                return False
+        return not self.timed_out()
+
+    def timed_out(self):
+        t = C.c_int32()
+        _lib.check(self.engine.lib.vaek_comm_status(self.engine.h, C.byref(t)))
+        return bool(t.value)
+
     def all_reduce(self, grads: torch.Tensor):
-        """SUM over ranks, in place."""
+        """SUM over ranks, in place (RCCL / gloo)."""
         if self.world == 1:
             return grads
         self.dist.all_reduce(grads, op=self.dist.ReduceOp.SUM)
