@@ -19,12 +19,15 @@ LOSS_RTOL = 1e-5
 GRAD_RTOL = 2e-5
 
 
-@pytest.mark.parametrize("force_generic", [True, False])
+PATHS = {"generic": dict(force_generic=True), "mfma": dict(fused_impl="mfma"), "valu": dict(fused_impl="valu")}
+
+
+@pytest.mark.parametrize("path", list(PATHS))
 @pytest.mark.parametrize("name", list(CASES))
-def test_golden_train_steps(name, force_generic):
+def test_golden_train_steps(name, path):
     cfg, dk, B, lr = build(name)
     f, meta = load_golden(name)
-    eng = engine_for(cfg, B, force_generic=force_generic)
+    eng = engine_for(cfg, B, **PATHS[path])
     check_layout(eng, cfg)
     params = dev(f["params0"])
     grads = eng.new_flat(eng.grad_len)
@@ -49,16 +52,16 @@ def test_golden_train_steps(name, force_generic):
     assert rel_err(host(v), f["v_final"]) <= 5e-5
 
 
-@pytest.mark.parametrize("force_generic", [True, False])
+@pytest.mark.parametrize("path", list(PATHS))
 @pytest.mark.parametrize("name,B", [("c1_linear_L20", 1000), ("c1_linear_L2", 257), ("sigmoid_linear", 300),
                                     ("c2_sigmoid_mlp", 515), ("c3_sphere_mlp", 1000), ("c4_linear_wide", 130),
-                                    ("linear_notdv", 64)])
-def test_seeded_grads_vs_oracle(name, B, force_generic):
+                                    ("linear_notdv", 64), ("c1_linear_L20", 70000)])
+def test_seeded_grads_vs_oracle(name, B, path):
     """Ragged batch sizes (not multiples of the 64-row tiles) against the oracle on the same inputs."""
     cfg, dk, _, lr = build(name)
     p, x, z1, z2 = random_problem(cfg, dk, B)
     loss, g = O.loss_and_grad(cfg, p, x, z1, z2)
-    eng = engine_for(cfg, B, force_generic=force_generic)
+    eng = engine_for(cfg, B, **PATHS[path])
     params = dev(O.flatten(cfg, p))
     grads = eng.new_flat(eng.grad_len)
     step = torch.zeros(1, dtype=torch.int32, device="cuda")

@@ -117,7 +117,7 @@ int vaek_comm_allreduce(vaek_ctx* ctx, float* buf, int64_t n, void* stream) {
     const unsigned epoch = ++ctx->comm.epoch;       // host-side counter: not for graph capture (the fused
                                                     // train step uses the device Adam step instead)
     ProfScope ps("p2p_allreduce", (hipStream_t)stream);
-    hipLaunchKernelGGL(p2p_allreduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    launch_k(ps, p2p_allreduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        comm_dev(ctx, 1), buf, (long long)n, epoch);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;

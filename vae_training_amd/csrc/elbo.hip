@@ -75,10 +75,10 @@ int launch_elbo(const ElboArgs& a, hipStream_t st) {
     const bool sig = a.y_sig != nullptr, grads = a.d_lin != nullptr;
     ProfScope ps("elbo", st);
     dim3 grid(a.S), block(256);
-    if (sig && grads) hipLaunchKernelGGL((elbo_kernel<true, true>), grid, block, 0, st, a);
-    else if (sig) hipLaunchKernelGGL((elbo_kernel<true, false>), grid, block, 0, st, a);
-    else if (grads) hipLaunchKernelGGL((elbo_kernel<false, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((elbo_kernel<false, false>), grid, block, 0, st, a);
+    if (sig && grads) launch_k(ps, (elbo_kernel<true, true>), grid, block, 0, st, a);
+    else if (sig) launch_k(ps, (elbo_kernel<true, false>), grid, block, 0, st, a);
+    else if (grads) launch_k(ps, (elbo_kernel<false, true>), grid, block, 0, st, a);
+    else launch_k(ps, (elbo_kernel<false, false>), grid, block, 0, st, a);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
 }
@@ -114,7 +114,7 @@ int launch_reparam_bwd(float* dsamp, const float* mu, const float* z1, float* pa
                        int rows, int L, int S, int rows_per_split, float inv_bt, hipStream_t st) {
     if (L > 256) { set_error("latent_dim %d > 256 not supported by reparam_bwd", L); return VAEK_ERR_INVALID; }
     ProfScope ps("reparam_bwd", st);
-    hipLaunchKernelGGL(reparam_bwd_kernel, dim3(S), dim3(256), 256 * sizeof(float), st, dsamp, mu, z1, partial,
+    launch_k(ps, reparam_bwd_kernel, dim3(S), dim3(256), 256 * sizeof(float), st, dsamp, mu, z1, partial,
                        rows, L, rows_per_split, inv_bt);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const FinalizeArgs a) {
 int launch_finalize(const FinalizeArgs& a, hipStream_t st) {
     const long long n = a.P + kExtra;
     ProfScope ps(a.params_rw ? "finalize_adam" : "finalize", st);
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    launch_k(ps, finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
 }
@@ -210,7 +210,7 @@ int launch_adam(float* params, const float* grads, float* m, float* v, int64_t n
     if (n <= 0) return VAEK_OK;
     const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
     ProfScope ps("adam", st);
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, params, grads, m, v, (long long)n, lr, step,
+    launch_k(ps, adam_kernel, dim3(blocks), dim3(256), 0, st, params, grads, m, v, (long long)n, lr, step,
                        step_dev, grad_scale);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
@@ -232,7 +232,8 @@ int launch_add_noise(const float* y_lin, const float* y_sig, const float* z2, co
                      float eps_cli, float* x_hat, int64_t n, hipStream_t st) {
     if (n <= 0) return VAEK_OK;
     const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
-    hipLaunchKernelGGL(add_noise_kernel, dim3(blocks), dim3(256), 0, st, y_lin, y_sig, z2, eps_param, eps_cli,
+    ProfScope ps("add_noise", st);
+    launch_k(ps, add_noise_kernel, dim3(blocks), dim3(256), 0, st, y_lin, y_sig, z2, eps_param, eps_cli,
                        x_hat, (long long)n);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
@@ -260,7 +261,8 @@ __global__ __launch_bounds__(64) void out4_kernel(const float* partial, int S, c
 
 int launch_elbo_out4(const float* partial, int S, const float* lv, int L, int D,
                      float eps, float rows, float inv_bt, float* out4, hipStream_t st) {
-    hipLaunchKernelGGL(out4_kernel, dim3(1), dim3(64), 0, st, partial, S, lv,
+    ProfScope ps("out4", st);
+    launch_k(ps, out4_kernel, dim3(1), dim3(64), 0, st, partial, S, lv,
                        (const float*)nullptr, eps, L, D, rows, inv_bt, out4, 1);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
@@ -269,7 +271,8 @@ int launch_elbo_out4(const float* partial, int S, const float* lv, int L, int D,
 int launch_eval_out4(const float* partial, int S, const float* params, int64_t off_epsp,
                      int64_t off_eps, int L, int D, float eps_cli, float rows, float inv_bt, float* out4,
                      hipStream_t st) {
-    hipLaunchKernelGGL(out4_kernel, dim3(1), dim3(64), 0, st, partial, S, params + off_epsp,
+    ProfScope ps("out4", st);
+    launch_k(ps, out4_kernel, dim3(1), dim3(64), 0, st, partial, S, params + off_epsp,
                        off_eps >= 0 ? params + off_eps : (const float*)nullptr, eps_cli, L, D, rows, inv_bt,
                        out4, 0);
     VAEK_HIP_CHECK(hipGetLastError());
@@ -287,7 +290,8 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* slabs, long
 
 int launch_sum_slabs(const float* slabs, int64_t stride, int S, float* out, int64_t n, hipStream_t st) {
     if (n <= 0) return VAEK_OK;
-    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slabs,
+    ProfScope ps("sum_slabs", st);
+    launch_k(ps, sum_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slabs,
                        (long long)stride, S, out, (long long)n);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;

@@ -1,0 +1,517 @@
+// Fused linear-VAE train step, matrix-core formulation (the metric's kernel).
+//
+// Same contract as fused_linear_kernel (fused_small.hip): x, z1, z2 read from HBM exactly once, one
+// partial gradient row per workgroup, no atomics.  What changes is WHERE the 1 200 FMAs per sample run.
+// The VALU formulation needs every weight as a per-lane register operand: 532 dwords LDS->VGPR per lane
+// and step, which at one wave per SIMD (B = 65 536 -> 256 samples per CU) makes the kernel LDS-bound.
+// Here the whole forward/backward chain runs on v_mfma_f32_16x16x4_f32 (exact f32 fmaf chains) in the
+// TRANSPOSED orientation -- features on the MFMA rows, 16 samples on the columns:
+//
+//     muT [L x16] = We^T [L xD] . xT [D x16]        A = weights (a few VGPRs per lane, loaded once),
+//     yT  [D x16] = Wd^T [D xL] . samplesT [L x16]   B = the previous product's ACCUMULATOR registers:
+//     gT  [L x16] = Wd   [L xD] . dyT [D x16]        lane (sample j, group g) register r of a 16-row block
+//                                                     is exactly the B operand of k-step r, so products
+//                                                     chain with no LDS, no shuffles, no re-layout.
+//
+// Row numbering inside a 16-row block is chosen per block: a FULL block uses feature = 16b + 4g + r (each
+// lane's 4 registers are 4 consecutive features -> float4 loads of z1); a PARTIAL block uses
+// 16b + 4r + g, which packs `rem` features into ceil(rem/4) registers = ceil(rem/4) k-steps (L = 20:
+// block 1 costs 1 step, not 4; D = 12: 3 steps).  Elementwise work (reparameterisation, residual, dy,
+// dmu, loss terms) happens in that accumulator layout, one sample per lane-column.
+//
+// The batch-reduction GEMMs samples^T dy and x^T dmu need the sample index on the K axis instead, i.e. a
+// transpose: each lane drops its 16 values per 16-sample sub-tile into the feature-major LDS image
+// T[feature][sample] (row stride = 2 mod 32 banks) and the wave reads its own 64 columns back as MFMA
+// operands.  Bias / epsilon_p gradients are column sums: accumulated per lane, reduced over the 16
+// lanes of a row with DPP-class shuffles once per kernel.
+#include "comm_dev.h"
+#include "vaek_internal.h"
+
+namespace vaek {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+#ifdef VAEK_STAMPS
+#define VAEK_MSTAMP(i)                                                                       \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        unsigned long long _t;                                                               \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); \
+        if (a.stamps && (threadIdx.x & 63) == 0) a.stamps[((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (i)] = _t; \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+    } while (0)
+#else
+#define VAEK_MSTAMP(i) do {} while (0)
+#endif
+
+// ---- block geometry of a feature axis of padded length N (<= 32) ----------------------------------
+template <int N>
+struct Axis {
+    static constexpr int NB = (N + 15) / 16;
+    static constexpr bool full(int b) { return N - 16 * b >= 16; }
+    static constexpr int rem(int b) { return N - 16 * b >= 16 ? 16 : N - 16 * b; }
+    static constexpr int nreg(int b) { return full(b) ? 4 : (rem(b) + 3) / 4; }     // registers = k-steps used
+    // feature held by lane group g, register r of block b
+    static __device__ __forceinline__ constexpr int feat(int b, int g, int r) { return full(b) ? 16 * b + 4 * g + r : 16 * b + 4 * r + g; }
+};
+
+template <int DP, int LP, bool SIG>
+struct MGeom {
+    using AD = Axis<DP>;
+    using AL = Axis<LP>;
+    static constexpr int TILE = 256, NW = 4, NSUB = 4;
+    static constexpr int TS = TILE + 2;
+    static constexpr int NB1 = DP * (SIG ? 2 : 1);
+    static constexpr int FS = 0, FX = FS + LP, FDY = FX + DP, FDM = FDY + NB1, NF = FDM + LP;
+    static constexpr int IB1 = (LP + 15) / 16, JB1 = (NB1 + 15) / 16, IB2 = (DP + 15) / 16, JB2 = (LP + 15) / 16;
+    static constexpr int NBLK = IB1 * JB1 + IB2 * JB2;
+    static constexpr int NF_PAD = FDM + JB2 * 16;
+    static constexpr int T_FLOATS = NF_PAD * TS;
+    // cross-wave reduction image: MFMA blocks, then column sums [dy | dys | dmu | gz], then 3 scalars
+    static constexpr int NCS = NB1 + 2 * LP;
+    static constexpr int R_PER_WAVE = NBLK * 256 + NCS + 4;
+    static constexpr int R_FLOATS = NW * R_PER_WAVE;
+    static constexpr int LDS_FLOATS = (T_FLOATS > R_FLOATS ? T_FLOATS : R_FLOATS);
+};
+
+template <int DP, int LP, bool SIG, bool EXACT>
+__global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __restrict__ params, const FusedArgs a) {
+    using G = MGeom<DP, LP, SIG>;
+    using AD = typename G::AD;
+    using AL = typename G::AL;
+    constexpr int NDB = AD::NB, NLB = AL::NB, NSUB = G::NSUB;
+    extern __shared__ __attribute__((aligned(16))) float T[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int j = lane & 15, g = lane >> 4;           // B/C layout: sample column j, row group g
+    const int ai = lane & 15, akg = lane >> 4;        // A layout: output row ai, k group akg
+    const int D = EXACT ? DP : a.D, L = EXACT ? LP : a.L;      // EXACT: every bound below folds at compile time
+    const int off_be = D * L, off_wd = off_be + L, off_bd = off_wd + L * D, off_ws = off_bd + D, off_bs = off_ws + L * D;
+    const int off_epsp = SIG ? off_bs + D : off_ws;
+    const bool vecD = D % 4 == 0, vecL = L % 4 == 0;
+
+    // ---- inputs of this wave's 64 samples, in accumulator layout, straight from HBM ----------------
+    float xv[NSUB][NDB][4], z2v[NSUB][NDB][4], z1v[NSUB][NLB][4];
+    bool valid[NSUB];
+    auto load_inputs = [&](int tile) {
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            const long long b = (long long)tile * G::TILE + wave * 64 + s * 16 + j;
+            valid[s] = b < a.B;
+            const float* px = a.x + b * D; const float* pz2 = a.z2 + b * D; const float* pz1 = a.z1 + b * L;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { xv[s][db][r] = 0.f; z2v[s][db][r] = 0.f; }
+                if (!valid[s]) continue;
+                if (AD::full(db) && vecD) {
+                    const int d0 = AD::feat(db, g, 0);
+                    if (d0 < D) {
+                        const float4 u = *reinterpret_cast<const float4*>(px + d0);
+                        const float4 w = *reinterpret_cast<const float4*>(pz2 + d0);
+                        xv[s][db][0] = u.x; xv[s][db][1] = u.y; xv[s][db][2] = u.z; xv[s][db][3] = u.w;
+                        z2v[s][db][0] = w.x; z2v[s][db][1] = w.y; z2v[s][db][2] = w.z; z2v[s][db][3] = w.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < AD::nreg(db); ++r) {
+                        const int d = AD::feat(db, g, r);
+                        if (d < D) { xv[s][db][r] = px[d]; z2v[s][db][r] = pz2[d]; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int lb = 0; lb < NLB; ++lb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z1v[s][lb][r] = 0.f;
+                if (!valid[s]) continue;
+                if (AL::full(lb) && vecL) {
+                    const int l0 = AL::feat(lb, g, 0);
+                    if (l0 < L) {
+                        const float4 u = *reinterpret_cast<const float4*>(pz1 + l0);
+                        z1v[s][lb][0] = u.x; z1v[s][lb][1] = u.y; z1v[s][lb][2] = u.z; z1v[s][lb][3] = u.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < AL::nreg(lb); ++r) {
+                        const int l = AL::feat(lb, g, r);
+                        if (l < L) z1v[s][lb][r] = pz1[l];
+                    }
+                }
+            }
+        }
+    };
+    load_inputs(blockIdx.x);
+
+    // ---- weights as MFMA A operands (lane = output row ai, k group akg), zero outside [D, L] -------
+    // row ai of a block <-> (g', r') = (ai >> 2, ai & 3)
+    auto latrow = [&](int lb) { return AL::feat(lb, ai >> 2, ai & 3); };
+    auto datrow = [&](int db) { return AD::feat(db, ai >> 2, ai & 3); };
+    float wmu[NLB][NDB][4], wy[NDB][NLB][4], wg[NLB][NDB][4], wys[SIG ? NDB : 1][NLB][4], wgs[SIG ? NLB : 1][NDB][4];
+#pragma unroll
+    for (int lb = 0; lb < NLB; ++lb)
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                // mu: out row = latent latrow(lb), k = data dim feat(db, akg, s);  g: same roles, weights Wd
+                const int lo = latrow(lb), dk = AD::feat(db, akg, s);
+                const bool ok = s < AD::nreg(db) && (ai & 3) < AL::nreg(lb) && lo < L && dk < D;
+                wmu[lb][db][s] = ok ? params[dk * L + lo] : 0.f;
+                wg[lb][db][s] = ok ? params[off_wd + lo * D + dk] : 0.f;
+                if (SIG) wgs[lb][db][s] = ok ? params[off_ws + lo * D + dk] : 0.f;
+                // y: out row = data dim datrow(db), k = latent feat(lb, akg, s)
+                const int dout = datrow(db), lk = AL::feat(lb, akg, s);
+                const bool ok2 = s < AL::nreg(lb) && (ai & 3) < AD::nreg(db) && dout < D && lk < L;
+                wy[db][lb][s] = ok2 ? params[off_wd + lk * D + dout] : 0.f;
+                if (SIG) wys[db][lb][s] = ok2 ? params[off_ws + lk * D + dout] : 0.f;
+            }
+    // per-lane constants in accumulator layout (group g, register r)
+    float c_be[NLB][4], c_sd[NLB][4], c_bd[NDB][4], c_bs[SIG ? NDB : 1][4];
+#pragma unroll
+    for (int lb = 0; lb < NLB; ++lb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int l = AL::feat(lb, g, r);
+            const bool ok = r < AL::nreg(lb) && l < L;
+            c_be[lb][r] = ok ? params[off_be + l] : 0.f;
+            c_sd[lb][r] = ok ? expf(0.5f * params[off_epsp + l]) : 0.f;      // e^{lv/2}, networks.py:73
+        }
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int d = AD::feat(db, g, r);
+            const bool ok = r < AD::nreg(db) && d < D;
+            c_bd[db][r] = ok ? params[off_bd + d] : 0.f;
+            if (SIG) c_bs[db][r] = ok ? params[off_bs + d] : 0.f;
+        }
+    const float eps = a.off_eps >= 0 ? params[a.off_eps] * a.eps_cli : a.eps_cli;
+    const float inv_var = expf(-eps), sigma = expf(0.5f * eps);
+    const float dscale = inv_var * a.inv_bt;
+
+    f32x4 acc1[G::IB1][G::JB1], acc2[G::IB2][G::JB2];
+#pragma unroll
+    for (int i = 0; i < G::IB1; ++i)
+#pragma unroll
+        for (int jj = 0; jj < G::JB1; ++jj) acc1[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < G::IB2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < G::JB2; ++jj) acc2[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float cs_dy[NDB][4], cs_dys[SIG ? NDB : 1][4], cs_dmu[NLB][4], cs_gz[NLB][4];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { cs_dy[db][r] = 0.f; if (SIG) cs_dys[db][r] = 0.f; }
+#pragma unroll
+    for (int lb = 0; lb < NLB; ++lb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { cs_dmu[lb][r] = 0.f; cs_gz[lb][r] = 0.f; }
+    float s_mse = 0.f, s_deps = 0.f, s_musq = 0.f;
+    VAEK_MSTAMP(0);
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        if (tile != (int)blockIdx.x) load_inputs(tile);
+        VAEK_MSTAMP(1);
+        // ---- mu^T = We^T x^T + be : the four 16-sample sub-tiles are independent MFMA chains ----------
+        f32x4 mu[NSUB][NLB];
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+            for (int lb = 0; lb < NLB; ++lb) mu[s][lb] = f32x4{c_be[lb][0], c_be[lb][1], c_be[lb][2], c_be[lb][3]};
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int k = 0; k < AD::nreg(db); ++k)
+#pragma unroll
+                for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+                    for (int lb = 0; lb < NLB; ++lb)
+                        mu[s][lb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wmu[lb][db][k], xv[s][db][k], mu[s][lb], 0, 0, 0);
+        // ---- samples = mu + e^{lv/2} z1 (networks.py:73-74), in accumulator layout ---------------------
+        float sv[NSUB][NLB][4];
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+            for (int lb = 0; lb < NLB; ++lb)
+#pragma unroll
+                for (int r = 0; r < AL::nreg(lb); ++r) {
+                    const float m = mu[s][lb][r];
+                    sv[s][lb][r] = fmaf(c_sd[lb][r], z1v[s][lb][r], m);
+                    s_musq = valid[s] ? fmaf(m, m, s_musq) : s_musq;
+                }
+        VAEK_MSTAMP(2);
+        // ---- y^T = Wd^T samples^T + bd (and the sigmoid head): B operand = the registers above ----------
+        f32x4 y[NSUB][NDB], ys[SIG ? NSUB : 1][NDB];
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                y[s][db] = f32x4{c_bd[db][0], c_bd[db][1], c_bd[db][2], c_bd[db][3]};
+                if (SIG) ys[s][db] = f32x4{c_bs[db][0], c_bs[db][1], c_bs[db][2], c_bs[db][3]};
+            }
+#pragma unroll
+        for (int lb = 0; lb < NLB; ++lb)
+#pragma unroll
+            for (int k = 0; k < AL::nreg(lb); ++k)
+#pragma unroll
+                for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db) {
+                        y[s][db] = __builtin_amdgcn_mfma_f32_16x16x4f32(wy[db][lb][k], sv[s][lb][k], y[s][db], 0, 0, 0);
+                        if (SIG) ys[s][db] = __builtin_amdgcn_mfma_f32_16x16x4f32(wys[db][lb][k], sv[s][lb][k], ys[s][db], 0, 0, 0);
+                    }
+        // ---- residual, loss terms, dL/dx_hat (networks.py:81-83, :94-98) -------------------------------
+        float dyv[NSUB][NDB][4], dysv[SIG ? NSUB : 1][NDB][4];
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int r = 0; r < AD::nreg(db); ++r) {
+                    const int d = AD::feat(db, g, r);
+                    float xh = fmaf(sigma, z2v[s][db][r], y[s][db][r]);
+                    float sg = 0.f;
+                    if (SIG) { sg = 1.f / (1.f + expf(-ys[s][db][r])); xh += sg; }
+                    const float rr = (valid[s] && d < D) ? xh - xv[s][db][r] : 0.f;
+                    const float q = rr * rr * inv_var;
+                    s_mse = fmaf(0.5f, q, s_mse);
+                    s_deps += -0.5f * q + 0.5f * sigma * z2v[s][db][r] * rr * inv_var;
+                    const float dyd = rr * dscale;
+                    dyv[s][db][r] = dyd;
+                    cs_dy[db][r] += dyd;
+                    if (SIG) { const float ds = dyd * sg * (1.f - sg); dysv[s][db][r] = ds; cs_dys[db][r] += ds; }
+                }
+        VAEK_MSTAMP(3);
+        // ---- g^T = Wd dy^T (+ Ws dys^T) ------------------------------------------------------------------
+        f32x4 gq[NSUB][NLB];
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+            for (int lb = 0; lb < NLB; ++lb) gq[s][lb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int k = 0; k < AD::nreg(db); ++k)
+#pragma unroll
+                for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+                    for (int lb = 0; lb < NLB; ++lb) {
+                        gq[s][lb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wg[lb][db][k], dyv[s][db][k], gq[s][lb], 0, 0, 0);
+                        if (SIG) gq[s][lb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wgs[lb][db][k], dysv[s][db][k], gq[s][lb], 0, 0, 0);
+                    }
+        // ---- dmu, column sums, and the feature-major image for the batch-reduction GEMMs ------------------
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            float* Tc = T + wave * 64 + s * 16 + j;
+#pragma unroll
+            for (int lb = 0; lb < NLB; ++lb)
+#pragma unroll
+                for (int r = 0; r < AL::nreg(lb); ++r) {
+                    const int l = AL::feat(lb, g, r);
+                    const float gl = gq[s][lb][r];
+                    const float dmu = valid[s] ? fmaf(mu[s][lb][r], a.inv_bt, gl) : 0.f;     // dmu = g + mu/B
+                    cs_dmu[lb][r] += dmu;
+                    cs_gz[lb][r] = fmaf(gl, z1v[s][lb][r], cs_gz[lb][r]);                     // reparam part of d lv
+                    if (l < LP) { Tc[(G::FS + l) * G::TS] = sv[s][lb][r]; Tc[(G::FDM + l) * G::TS] = dmu; }
+                }
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int r = 0; r < AD::nreg(db); ++r) {
+                    const int d = AD::feat(db, g, r);
+                    if (d < DP) {
+                        Tc[(G::FX + d) * G::TS] = xv[s][db][r];
+                        Tc[(G::FDY + d) * G::TS] = dyv[s][db][r];
+                        if (SIG) Tc[(G::FDY + DP + d) * G::TS] = dysv[s][db][r];
+                    }
+                }
+        }
+        // each wave reads back only its own 64 columns: wave-level ordering is enough (no s_barrier)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        VAEK_MSTAMP(4);
+        // ---- dWd (+dWs) = samples^T [dy|dys],  dWe = x^T dmu : K = the wave's 64 samples ------------------
+        {
+            const float* Tk = T + wave * 64 + (lane >> 4) + (lane & 15) * G::TS;
+            constexpr int NOP = G::IB1 + G::JB1 + G::IB2 + G::JB2;
+            // Operand prefetch runs ONE group of GS k-steps ahead: lgkmcnt is a 4-bit counter, so the wait
+            // in front of a group's MFMAs can only be exact while <= 15 younger reads are in flight.
+            constexpr int GS = (2 * NOP <= 15) ? 2 : 1, NG = 16 / GS;
+            float op[2][GS][NOP];
+            auto load_group = [&](int gi, int which) {
+#pragma unroll
+                for (int u = 0; u < GS; ++u) {
+                    const int s4 = 4 * (gi * GS + u);
+                    int n = 0;
+#pragma unroll
+                    for (int i = 0; i < G::IB1; ++i) op[which][u][n++] = Tk[(G::FS + 16 * i) * G::TS + s4];
+#pragma unroll
+                    for (int jj = 0; jj < G::JB1; ++jj) op[which][u][n++] = Tk[(G::FDY + 16 * jj) * G::TS + s4];
+#pragma unroll
+                    for (int i = 0; i < G::IB2; ++i) op[which][u][n++] = Tk[(G::FX + 16 * i) * G::TS + s4];
+#pragma unroll
+                    for (int jj = 0; jj < G::JB2; ++jj) op[which][u][n++] = Tk[(G::FDM + 16 * jj) * G::TS + s4];
+                }
+            };
+            load_group(0, 0);
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                if (gi + 1 < NG) load_group(gi + 1, (gi + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < GS; ++u) {
+                    const float* o = op[gi & 1][u];
+#pragma unroll
+                    for (int i = 0; i < G::IB1; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < G::JB1; ++jj)
+                            acc1[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[i], o[G::IB1 + jj], acc1[i][jj], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < G::IB2; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < G::JB2; ++jj)
+                            acc2[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[G::IB1 + G::JB1 + i], o[G::IB1 + G::JB1 + G::IB2 + jj],
+                                                                               acc2[i][jj], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    VAEK_MSTAMP(5);
+
+    // ---- epilogue: column sums over the 16 lanes of a row, cross-wave sum through LDS, one partial row ---
+    // all-reduce over the 16 lanes of a DPP row (= the 16 sample columns of one row group): v += ror(v, n)
+    // as ONE v_add_f32 with a row_ror modifier each -- __shfl_xor would go through the LDS crossbar
+    auto rowsum = [&](float v) {
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+        return v;
+    };
+    __syncthreads();           // every wave is done with its T columns before T is reused as R
+    float* R = T + wave * G::R_PER_WAVE;
+    {
+        const int col = lane & 15, row0 = 4 * (lane >> 4);
+        int blk = 0;
+#pragma unroll
+        for (int i = 0; i < G::IB1; ++i)
+#pragma unroll
+            for (int jj = 0; jj < G::JB1; ++jj, ++blk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) R[(blk * 16 + row0 + r) * 16 + col] = acc1[i][jj][r];
+#pragma unroll
+        for (int i = 0; i < G::IB2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < G::JB2; ++jj, ++blk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) R[(blk * 16 + row0 + r) * 16 + col] = acc2[i][jj][r];
+        float* CS = R + G::NBLK * 256;     // [dy (DP) | dys (DP)] [dmu (LP)] [gz (LP)]
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < AD::nreg(db); ++r) {
+                const int d = AD::feat(db, g, r);
+                const float v = rowsum(cs_dy[db][r]);
+                float vs = 0.f;
+                if (SIG) vs = rowsum(cs_dys[db][r]);
+                if (j == 0 && d < DP) { CS[d] = v; if (SIG) CS[DP + d] = vs; }
+            }
+#pragma unroll
+        for (int lb = 0; lb < NLB; ++lb)
+#pragma unroll
+            for (int r = 0; r < AL::nreg(lb); ++r) {
+                const int l = AL::feat(lb, g, r);
+                const float v = rowsum(cs_dmu[lb][r]), w = rowsum(cs_gz[lb][r]);
+                if (j == 0 && l < LP) { CS[G::NB1 + l] = v; CS[G::NB1 + LP + l] = w; }
+            }
+        float m0 = rowsum(s_mse), m1 = rowsum(s_musq), m2 = rowsum(s_deps);      // 16 lanes by DPP, then the 4 rows
+#pragma unroll
+        for (int o = 32; o >= 16; o >>= 1) { m0 += __shfl_xor(m0, o, 64); m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64); }
+        if (lane == 0) { CS[G::NCS + 0] = m0; CS[G::NCS + 1] = m1; CS[G::NCS + 2] = m2; }
+    }
+    __syncthreads();
+    auto fetch = [&](int gemm, int i, int jj) -> float {
+        const int blk = gemm == 1 ? (i >> 4) * G::JB1 + (jj >> 4) : G::IB1 * G::JB1 + (i >> 4) * G::JB2 + (jj >> 4);
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < G::NW; ++w) v += T[w * G::R_PER_WAVE + (blk * 16 + (i & 15)) * 16 + (jj & 15)];
+        return v;
+    };
+    auto fetch_cs = [&](int k) -> float {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < G::NW; ++w) v += T[w * G::R_PER_WAVE + G::NBLK * 256 + k];
+        return v;
+    };
+    float* out = a.partials + (long long)blockIdx.x * a.pstride;
+    for (int idx = t; idx < a.P + kExtra; idx += 256) {
+        float v = 0.f;
+        if (idx < off_be) v = fetch(2, idx / L, idx % L);                              // dWe = x^T dmu
+        else if (idx < off_wd) v = fetch_cs(G::NB1 + idx - off_be);                    // dbe = 1^T dmu
+        else if (idx < off_bd) { const int k = idx - off_wd; v = fetch(1, k / D, k % D); }   // dWd = samples^T dy
+        else if (idx < off_bd + D) v = fetch_cs(idx - off_bd);                         // dbd = 1^T dy
+        else if (SIG && idx < off_bs) { const int k = idx - off_ws; v = fetch(1, k / D, DP + k % D); }
+        else if (SIG && idx < off_bs + D) v = fetch_cs(DP + idx - off_bs);
+        else if (idx >= off_epsp && idx < off_epsp + L) v = fetch_cs(G::NB1 + LP + idx - off_epsp);   // sum g*z1
+        else if (idx >= a.P && idx < a.P + 3) v = fetch_cs(G::NCS + idx - a.P);
+        out[idx] = v;
+    }
+    VAEK_MSTAMP(6);
+    if (blockIdx.x == 0 && t == 0 && a.step_dev) a.step_dev[0] += 1;
+}
+
+// ---- variant table ---------------------------------------------------------------------------------
+typedef void (*MfmaKernel)(const float*, const FusedArgs);
+struct MfmaVariant { int dp, lp, sig, exact; MfmaKernel fn; size_t lds_bytes; };
+#define VAEK_MFMA(DP, LP, SIG, EXACT) \
+    {DP, LP, SIG, EXACT, fused_linear_mfma_kernel<DP, LP, (SIG) != 0, (EXACT) != 0>, sizeof(float) * MGeom<DP, LP, (SIG) != 0>::LDS_FLOATS}
+
+static const MfmaVariant kMfmaVariants[] = {
+    // exact shapes of seed_linpadding_expts.sh (the metric's configuration first)
+    VAEK_MFMA(12, 20, 0, 1),
+#ifndef VAEK_FUSED_ONLY_M
+    VAEK_MFMA(20, 20, 0, 1), VAEK_MFMA(20, 10, 0, 1),
+    // zero-padded coverage of every other D, L <= 32
+    VAEK_MFMA(16, 16, 0, 0), VAEK_MFMA(32, 32, 0, 0), VAEK_MFMA(12, 4, 0, 0),
+    // sigmoid dataset (two decoders): sigmoid_vae_padding_expts.sh shapes
+    VAEK_MFMA(8, 8, 1, 0), VAEK_MFMA(12, 12, 1, 0), VAEK_MFMA(16, 16, 1, 0), VAEK_MFMA(20, 8, 1, 0), VAEK_MFMA(24, 16, 1, 0),
+    VAEK_MFMA(28, 24, 1, 1), VAEK_MFMA(32, 32, 1, 0),
+#endif
+};
+
+static const MfmaVariant* pick_mfma(const vaek_ctx* c) {
+    if (c->cfg.n_enc_hidden != 0 || c->cfg.n_dec_hidden != 0 || c->cfg.dtype != VAEK_F32) return nullptr;
+    const MfmaVariant* best = nullptr;
+    for (const auto& v : kMfmaVariants) {
+        if (v.sig != (c->cfg.sigmoid_decoder ? 1 : 0) || v.dp < c->D || v.lp < c->L || v.lds_bytes > 160 * 1024) continue;
+        if (v.exact && (v.dp != c->D || v.lp != c->L)) continue;
+        if (!best || v.dp * v.lp < best->dp * best->lp) best = &v;
+    }
+    return best;
+}
+
+bool fused_mfma_supported(const vaek_ctx* c) { return pick_mfma(c) != nullptr; }
+
+int fused_mfma_launch(const vaek_ctx* c, const float* params, const void* args_void, int grid, hipStream_t st) {
+    const MfmaVariant* var = pick_mfma(c);
+    if (!var) { set_error("mfma fused path not available"); return VAEK_ERR_INVALID; }
+    const FusedArgs& a = *static_cast<const FusedArgs*>(args_void);
+    static thread_local const void* lds_set[sizeof(kMfmaVariants) / sizeof(kMfmaVariants[0])] = {};
+    const size_t vi = var - kMfmaVariants;
+    if (var->lds_bytes > 64 * 1024 && lds_set[vi] == nullptr) {
+        VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)var->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)var->lds_bytes));
+        lds_set[vi] = (const void*)var->fn;
+    }
+    {
+        ProfScope ps("fused_linear_mfma", st);
+        launch_k(ps, var->fn, dim3(grid), dim3(256), var->lds_bytes, st, params, a);
+    }
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+}  // namespace vaek

@@ -26,16 +26,6 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 
-struct FusedArgs {
-    const float* x; const float* z1; const float* z2;
-    float* partials; int pstride;      // [grid][pstride]
-    int B, D, L, ntiles;
-    float inv_bt, eps_cli;
-    int off_be, off_wd, off_bd, off_ws, off_bs, off_epsp, off_eps, P;
-    int32_t* step_dev;
-    unsigned long long* stamps;        // diagnostic builds only (-DVAEK_STAMPS): [block][wave][8] s_memtime
-};
-
 // In-kernel phase stamps (cdna_hip_programming.md section 7): ONE asm statement, fenced for the scheduler.
 #ifdef VAEK_STAMPS
 #define VAEK_STAMP(i)                                                                        \
@@ -523,8 +513,12 @@ static const FusedVariant* pick_variant(const vaek_ctx* c) {
     return best;
 }
 
+// cfg.reserved[0]: 0 = matrix-core chain (fused_mfma.hip) where available, 1 = VALU chain (this file)
+static bool use_mfma(const vaek_ctx* c) { return c->cfg.reserved[0] != 1 && fused_mfma_supported(c); }
+static int fused_tile(const vaek_ctx* c, const FusedVariant* v) { return use_mfma(c) ? 256 : v->tile; }
 static int fused_grid(const vaek_ctx* c, const FusedVariant* v) {
-    const int ntiles = (c->B + v->tile - 1) / v->tile;
+    const int tile = fused_tile(c, v);
+    const int ntiles = (c->B + tile - 1) / tile;
     return std::max(1, std::min(ntiles, 2 * c->n_cu));
 }
 static int fused_pstride(const vaek_ctx* c) { return (int)((c->P + kExtra + 63) / 64 * 64); }
@@ -553,7 +547,7 @@ int fused_train_step(vaek_ctx* c, float* params, float* grads, float* m, float* 
     const int grid = fused_grid(c, var), pstride = fused_pstride(c);
     FusedArgs a{};
     a.x = x; a.z1 = z1; a.z2 = z2; a.partials = partials; a.pstride = pstride;
-    a.B = c->B; a.D = c->D; a.L = c->L; a.ntiles = (c->B + var->tile - 1) / var->tile;
+    a.B = c->B; a.D = c->D; a.L = c->L; a.ntiles = (c->B + fused_tile(c, var) - 1) / fused_tile(c, var);
     a.inv_bt = (float)(1.0 / (double)c->Bt); a.eps_cli = c->cfg.eps_cli;
     const int D = c->D, L = c->L;
     a.off_be = D * L; a.off_wd = a.off_be + L; a.off_bd = a.off_wd + L * D;
@@ -561,11 +555,14 @@ int fused_train_step(vaek_ctx* c, float* params, float* grads, float* m, float* 
     a.off_epsp = (int)c->off_epsp; a.off_eps = (int)c->off_eps; a.P = (int)c->P;
     a.step_dev = step_dev;
     a.stamps = c->dbg_stamps;
-    {
+    if (use_mfma(c)) {
+        int rc = fused_mfma_launch(c, params, &a, grid, st);
+        if (rc) return rc;
+    } else {
         ProfScope ps("fused_linear_fwd_bwd", st);
-        hipLaunchKernelGGL(var->fn, dim3(grid), dim3(var->tile), var->lds_bytes, st, (const float*)params, a);
+        launch_k(ps, var->fn, dim3(grid), dim3(var->tile), var->lds_bytes, st, (const float*)params, a);
+        VAEK_HIP_CHECK(hipGetLastError());
     }
-    VAEK_HIP_CHECK(hipGetLastError());
     FusedFinArgs f{};
     f.partials = partials; f.pstride = pstride; f.G = grid;
     f.P = (int)c->P; f.off_epsp = (int)c->off_epsp; f.off_eps = (int)c->off_eps; f.L = L; f.D = D;
@@ -577,7 +574,7 @@ int fused_train_step(vaek_ctx* c, float* params, float* grads, float* m, float* 
     if (exchange) f.comm = comm_dev(c, 0);
     {
         ProfScope ps(apply_adam ? "fused_finalize_adam" : "fused_finalize", st);
-        hipLaunchKernelGGL(fused_finalize_kernel, dim3((unsigned)((c->P + kExtra + 63) / 64)), dim3(1024), 0, st, f);
+        launch_k(ps, fused_finalize_kernel, dim3((unsigned)((c->P + kExtra + 63) / 64)), dim3(1024), 0, st, f);
     }
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;

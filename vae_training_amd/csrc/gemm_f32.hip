@@ -168,7 +168,7 @@ static int launch(const GemmArgs& g, int splits, hipStream_t st) {
         set_error("gemm grid too large (M=%d N=%d splits=%d)", g.M, g.N, splits);
         return VAEK_ERR_INVALID;
     }
-    hipLaunchKernelGGL((gemm_f32_kernel<A_KCONT, B_KCONT, EPI>), grid, dim3(NT), 0, st, g);
+    launch_k(ps, (gemm_f32_kernel<A_KCONT, B_KCONT, EPI>), grid, dim3(NT), 0, st, g);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
 }

@@ -50,18 +50,26 @@ struct Profiler {
     int n = 0, cap = 0;
 };
 extern thread_local Profiler* g_prof;    // set by the C entry points for the duration of a call
-struct ProfScope {                       // brackets one launch on `st`
-    hipStream_t st; int idx = -1;
-    ProfScope(const char* label, hipStream_t s) : st(s) {
+// One launch = one event pair, handed to hipExtLaunchKernelGGL so the timestamps are the kernel's own
+// begin/end (what rocprofv3 reports), not host-side record times (which would count submission gaps
+// into the ~5-10 us kernels of the metric workload).
+struct ProfScope {
+    int idx = -1;
+    ProfScope(const char* label, hipStream_t) {
         Profiler* p = g_prof;
-        if (p && p->on && p->n < p->cap) {
-            idx = p->n++;
-            p->label[idx] = label;
-            (void)hipEventRecord(p->ev[2 * idx], st);
-        }
+        if (p && p->on && p->n < p->cap) { idx = p->n++; p->label[idx] = label; }
     }
-    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof->ev[2 * idx + 1], st); }
+    hipEvent_t start() const { return g_prof->ev[2 * idx]; }
+    hipEvent_t stop() const { return g_prof->ev[2 * idx + 1]; }
 };
+}  // namespace vaek
+#include <hip/hip_ext.h>
+namespace vaek {
+template <typename K, typename... Args>
+inline void launch_k(const ProfScope& ps, K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t st, Args... args) {
+    if (ps.idx >= 0) hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, ps.start(), ps.stop(), 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, shmem, st, args...);
+}
 
 struct Comm {
     bool ready = false;
@@ -151,6 +159,19 @@ int launch_sum_slabs(const float* slabs, int64_t stride, int S, float* out, int6
 // ---- comm.hip -------------------------------------------------------------------------------
 struct CommDev;
 CommDev comm_dev(const vaek_ctx* c, int region);
+
+// ---- fused_small.hip / fused_mfma.hip: arguments of the fused linear-VAE kernels ----------------
+struct FusedArgs {
+    const float* x; const float* z1; const float* z2;
+    float* partials; int pstride;      // [grid][pstride]
+    int B, D, L, ntiles;
+    float inv_bt, eps_cli;
+    int off_be, off_wd, off_bd, off_ws, off_bs, off_epsp, off_eps, P;
+    int32_t* step_dev;
+    unsigned long long* stamps;        // diagnostic builds only (-DVAEK_STAMPS): [block][wave][8] s_memtime
+};
+bool fused_mfma_supported(const vaek_ctx* c);
+int fused_mfma_launch(const vaek_ctx* c, const float* params, const void* fused_args, int grid, hipStream_t st);
 
 // ---- fused_small.hip ----------------------------------------------------------------------
 bool fused_supported(const vaek_ctx* c);

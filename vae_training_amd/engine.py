@@ -35,7 +35,7 @@ class Engine:
 
     def __init__(self, batch, data_dim, latent_dim, enc_hidden=(), dec_hidden=(), epsilon=0.0,
                  tunable_decoder_var=False, sigmoid_decoder=False, device=None, world=1, rank=0,
-                 global_batch=0, dtype="f32", force_generic=False):
+                 global_batch=0, dtype="f32", force_generic=False, fused_impl="auto"):
         if not torch.cuda.is_available():
             raise RuntimeError("vae_training_amd needs an MI355X (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -59,6 +59,7 @@ class Engine:
         cfg.device = self.device.index
         cfg.world, cfg.rank, cfg.global_batch = int(world), int(rank), int(global_batch)
         cfg.force_generic = int(bool(force_generic))
+        cfg.reserved[0] = {"auto": 0, "mfma": 0, "valu": 1}[fused_impl]      # which fused linear-VAE kernel
         self.cfg = cfg
         h = C.c_void_p()
         _lib.check(self.lib.vaek_ctx_create(C.byref(cfg), C.byref(h)))
