@@ -271,8 +271,12 @@ def main():
                 alg = B_local * 4 * (2 * D + L)
                 peak, unit, bound = 8000.0, "GB/s", "hbm"
                 achieved = alg / avg_s / 1e9
+            traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh)
+            tfile = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{args.workload}.json")
+            if os.path.exists(tfile) and B_local == w["batch"]:
+                traffic = json.load(open(tfile))["kernels"].get(dom, {}).get("traffic_bytes")
             roofline = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
-                        "traffic": None, "kernel": dom, "kernel_avg_us": avg_s * 1e6,
+                        "traffic": traffic, "kernel": dom, "kernel_avg_us": avg_s * 1e6,
                         "launches_per_step": rep[dom]["count"] / args.steps,
                         "algorithmic_per_launch": alg,
                         "step_kernels_us": {k: r["total_ms"] / args.steps * 1e3 for k, r in rep.items()},
