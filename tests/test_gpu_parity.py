@@ -99,6 +99,33 @@ def test_forward_and_sampling(name):
     assert rel_err(host(gx2), xh[:37]) <= 1e-5
 
 
+def test_multi_tile_per_workgroup_and_wide_latent():
+    """B > 512 tiles x 256 rows makes the fused kernels loop over several tiles per workgroup; L = 100
+    exercises the separate-Adam branch of the layer-by-layer finalize."""
+    cfg = O.Config(12, 20, (), (), -1.0, True, "linear_gaussian")
+    B = 512 * 256 + 300
+    p, x, z1, z2 = random_problem(cfg, dict(name="linear_gaussian", seed=2, dd=3, did=3, pad=9), B)
+    loss, g = O.loss_and_grad(cfg, p, x, z1, z2)
+    for path in ("mfma", "valu"):
+        eng = engine_for(cfg, B, **PATHS[path])
+        grads = eng.new_flat(eng.grad_len)
+        step = torch.zeros(1, dtype=torch.int32, device="cuda")
+        eng.grads_only(dev(O.flatten(cfg, p)), grads, step, dev(x), dev(z1), dev(z2))
+        got = host(grads)
+        assert abs(got[eng.P] - loss) <= LOSS_RTOL * abs(loss), path
+        assert rel_err(got[:eng.P], O.flatten(cfg, g)) <= GRAD_RTOL, path
+    cfg = O.Config(40, 100, (48,), (48,), -1.0, True, "linear_gaussian")
+    B, lr = 300, 1e-3
+    p, x, z1, z2 = random_problem(cfg, dict(name="linear_gaussian", seed=2, dd=3, did=3, pad=37), B)
+    p_ref, _, loss = O.train_step(cfg, p, O.adam_init(p), x, z1, z2, lr)
+    eng = engine_for(cfg, B)
+    params = dev(O.flatten(cfg, p)); grads = eng.new_flat(eng.grad_len); m = eng.new_flat(); v = eng.new_flat()
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    eng.train_step(params, grads, m, v, step, dev(x), dev(z1), dev(z2), lr)
+    assert abs(host(grads)[eng.P] - loss) <= LOSS_RTOL * abs(loss)
+    assert np.max(np.abs(host(params) - O.flatten(cfg, p_ref))) <= 0.02 * lr
+
+
 def test_determinism_bitwise():
     cfg, dk, _, lr = build("c2_sigmoid_mlp")
     B = 4096

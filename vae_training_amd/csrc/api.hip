@@ -154,7 +154,14 @@ static int generic_finalize(vaek_ctx* c, const float* params, float* grads, floa
     f.rows_over_bt = (float)((double)c->B / (double)c->Bt); f.inv_bt = (float)(1.0 / (double)c->Bt);
     f.rows = (float)c->B;
     f.grads = grads; f.params_rw = params_rw; f.m = m; f.v = v; f.step_dev = step_dev; f.lr = lr;
-    return launch_finalize(f, st);
+    // Adam is fused into the finalize kernel only while epsilon_p, epsilon and the scalar sums all sit
+    // in its block 0 (64 outputs): the loss lanes read epsilon_p, so its Adam writers must be behind the
+    // same block-local barrier.  Wider latents take a separate Adam launch.
+    const bool fuse = params_rw != nullptr && c->L + 5 <= 64;
+    if (!fuse) f.params_rw = nullptr;
+    int rc = launch_finalize(f, st);
+    if (rc || params_rw == nullptr || fuse) return rc;
+    return launch_adam(params_rw, grads, m, v, c->P, lr, 0, step_dev, 1.f, st);
 }
 
 }  // namespace vaek

@@ -135,60 +135,90 @@ __device__ __forceinline__ void adam_bias_corrections(int t, float& bc1, float& 
     bc2 = -expm1f((float)t * -0.0010005003335835335f);
 }
 
-// Block b covers outputs [n - 256(b+1), n - 256b): epsilon_p, epsilon and the scalar sums (which
-// need each other, and whose parameters the loss reads) always sit together in block 0, so the
-// barrier between "every read of params" and "first Adam write" is block-local.  L <= 250.
-__global__ __launch_bounds__(256) void finalize_kernel(const FinalizeArgs a) {
-    __shared__ float sh[3][256];
-    const int t = threadIdx.x;
+// Block b covers outputs [n - 64(b+1), n - 64b): the scalar sums (and epsilon, which needs one of them)
+// always sit in block 0.  1024 threads = 64 outputs x 16 row groups: every thread walks its share of
+// the S dW|db slabs / Se elementwise partial rows with independent loads, then a fixed-order sum.
+constexpr int FINQ = 16;
+__global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeArgs a) {
+    __shared__ float part[FINQ][64];
+    __shared__ float sums[64];
+    __shared__ float klred[1024];
+    const int t = threadIdx.x, o = t & 63, q = t >> 6;
     const long long n = a.P + kExtra;
-    const long long i = n - 256ll * ((long long)blockIdx.x + 1) + t;
-    if (blockIdx.x == 0) {      // fixed-order cooperative sum of the elbo partials [Se][4]
-        float m0 = 0.f, m1 = 0.f, m2 = 0.f;
-        for (int s = t; s < a.Se; s += 256) { m0 += a.epart[s * 4 + 0]; m1 += a.epart[s * 4 + 1]; m2 += a.epart[s * 4 + 2]; }
-        sh[0][t] = m0; sh[1][t] = m1; sh[2][t] = m2;
-        __syncthreads();
-        for (int w = 128; w > 0; w >>= 1) {
-            if (t < w) { sh[0][t] += sh[0][t + w]; sh[1][t] += sh[1][t + w]; sh[2][t] += sh[2][t + w]; }
-            __syncthreads();
-        }
-    }
-    float g = 0.f;
+    const long long i = n - 64ll * ((long long)blockIdx.x + 1) + o;
+    // Adam state of this output is fetched up front, under the partial loads
+    const bool adam = a.params_rw != nullptr && q == 0 && i >= 0 && i < a.P;
+    float p_old = 0.f, m_old = 0.f, v_old = 0.f;
+    int tstep = 0;
+    if (adam) { p_old = a.params_rw[i]; m_old = a.m[i]; v_old = a.v[i]; tstep = a.step_dev[0]; }
+    float acc = 0.f;
     if (i >= 0 && i < a.P) {
         if (i == a.off_eps) {
-            // eps = param * eps_cli, networks.py:71; + 0.5 per (row, d) element is the constant part
-            g = a.eps_cli * (sh[2][0] + 0.5f * a.rows * (float)a.D) * a.inv_bt;
+            for (int s = q; s < a.Se; s += FINQ) acc += a.epart[s * 4 + 2];
         } else if (i >= a.off_epsp && i < a.off_epsp + a.L) {
-            for (int s = 0; s < a.Se; ++s) g += a.rpart[(long long)s * a.L + (i - a.off_epsp)];
-            const float lv = a.params[i];
-            g = 0.5f * expf(0.5f * lv) * g - 0.5f * (1.f - expf(lv)) * a.rows_over_bt;
+            const float* r = a.rpart + (i - a.off_epsp);
+            for (int s = q; s < a.Se; s += FINQ) acc += r[(long long)s * a.L];
         } else {
-            for (int s = 0; s < a.S; ++s) g += a.slabs[(long long)s * a.slab_stride + i];
+            const float* p = a.slabs + i;
+            for (int s = q; s < a.S; s += FINQ) acc += p[(long long)s * a.slab_stride];
         }
-    } else if (i >= a.P && i < a.P + 3) {
-        float klc = 0.f;   // sum_l (1 + lv - e^lv)
-        for (int l = 0; l < a.L; ++l) { const float lv = a.params[a.off_epsp + l]; klc += 1.f + lv - expf(lv); }
-        const float eps = a.off_eps >= 0 ? a.params[a.off_eps] * a.eps_cli : a.eps_cli;
-        const float dkl = (0.5f * sh[1][0] - 0.5f * a.rows * klc) * a.inv_bt;
-        const float mse = (sh[0][0] + 0.5f * a.rows * (float)a.D * (kLog2Pi + eps)) * a.inv_bt;
-        g = (i == a.P) ? dkl + mse : (i == a.P + 1 ? dkl : mse);
+    } else if (i == a.P || i == a.P + 1) {
+        for (int s = q; s < a.Se; s += FINQ) acc += a.epart[s * 4 + (int)(i - a.P)];      // sum mse terms, sum mu^2
     }
-    __syncthreads();            // every read of params above precedes every Adam write below
-    if (i < 0) return;
+    part[q][o] = acc;
+    float kl = 0.f;                                   // closed-form KL constant sum_l (1 + lv - e^lv), block 0 only
+    if (blockIdx.x == 0) for (int l = t; l < a.L; l += 1024) { const float lv = a.params[a.off_epsp + l]; kl += 1.f + lv - expf(lv); }
+    klred[t] = kl;
+    const float eps_par = a.off_eps >= 0 ? a.params[a.off_eps] : 0.f;
+    const float lv_own = (q == 0 && i >= a.off_epsp && i < a.off_epsp + a.L) ? a.params[i] : 0.f;
+    __syncthreads();
+    if (q == 0) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int u = 0; u < FINQ; ++u) sacc += part[u][o];
+        sums[o] = sacc;
+    }
+    if (blockIdx.x == 0) {
+        for (int w = 512; w > 0; w >>= 1) { if (t < w) klred[t] += klred[t + w]; __syncthreads(); }
+    } else {
+        __syncthreads();
+    }
+    const bool live = q == 0 && i >= 0;
+    float g = live ? sums[o] : 0.f;
+    const long long base = n - 64ll * ((long long)blockIdx.x + 1);
+    if (!live) {
+    } else if (i == a.off_eps) {
+        // eps = param * eps_cli, networks.py:71; + 0.5 per (row, d) element is the constant part
+        g = a.eps_cli * (g + 0.5f * a.rows * (float)a.D) * a.inv_bt;
+    } else if (i >= a.off_epsp && i < a.off_epsp + a.L) {
+        g = 0.5f * expf(0.5f * lv_own) * g - 0.5f * (1.f - expf(lv_own)) * a.rows_over_bt;
+    } else if (i >= a.P) {
+        if (i < a.P + 3) {
+            const float eps = a.off_eps >= 0 ? eps_par * a.eps_cli : a.eps_cli;
+            const float dkl = (0.5f * sums[a.P + 1 - base] - 0.5f * a.rows * klred[0]) * a.inv_bt;
+            const float mse = (sums[a.P - base] + 0.5f * a.rows * (float)a.D * (kLog2Pi + eps)) * a.inv_bt;
+            g = (i == a.P) ? dkl + mse : (i == a.P + 1 ? dkl : mse);
+        } else {
+            g = 0.f;
+        }
+    }
+    __syncthreads();            // every read of params above precedes every Adam write below (block-local:
+                                // the loss lanes live in block 0 and read only epsilon_p / epsilon, whose
+                                // writers run after this barrier in block 0 or never touch those leaves)
+    if (!live) return;
     a.grads[i] = g;
-    if (a.params_rw && i < a.P) {
+    if (adam) {
         float bc1, bc2;
-        adam_bias_corrections(a.step_dev[0], bc1, bc2);
-        float p = a.params_rw[i], m = a.m[i], v = a.v[i];
-        adam_apply(p, g, m, v, a.lr, bc1, bc2);
-        a.params_rw[i] = p; a.m[i] = m; a.v[i] = v;
+        adam_bias_corrections(tstep, bc1, bc2);
+        adam_apply(p_old, g, m_old, v_old, a.lr, bc1, bc2);
+        a.params_rw[i] = p_old; a.m[i] = m_old; a.v[i] = v_old;
     }
 }
 
 int launch_finalize(const FinalizeArgs& a, hipStream_t st) {
     const long long n = a.P + kExtra;
     ProfScope ps(a.params_rw ? "finalize_adam" : "finalize", st);
-    launch_k(ps, finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    launch_k(ps, finalize_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, st, a);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
 }
