@@ -170,6 +170,23 @@ int vaek_comm_allreduce(vaek_ctx* ctx, float* buf, int64_t n, void* stream);
 /* Synchronous: *timed_out = 1 if any exchange on this rank ever gave up waiting for a peer. */
 int vaek_comm_status(vaek_ctx* ctx, int32_t* timed_out);
 
+/* ---- inputs of the hot path, generated on the device ---------------------- */
+/* One Philox4x32-10 kernel replacing dataset.get_batch (datasets.py:75-84 sphere = kind 2, :183-195
+ * linear_gaussian = kind 0 with A[dd][did], :240-249 sigmoid = kind 1 with A[dd]) and the latent draw
+ * of model.py:225-228 split as vae.py:127-128 does (z1[rows,L], z2[rows,D]).  Row i of the call draws
+ * from counter (row0 + i, block, step, tag) under key `seed`: reproducible, shardable by rows, and
+ * graph-replayable when `step_dev` (the device Adam step counter) is given instead of step_host.
+ * x may be NULL (latents only).  dd, did <= 16; tag < 2^30. */
+int vaek_make_batch(vaek_ctx* ctx, int32_t kind, const float* A, int32_t dd, int32_t did, int32_t pad, float var_added,
+                    float* x, float* z1, float* z2, int32_t rows, int64_t row0, uint64_t seed,
+                    const int32_t* step_dev, uint32_t step_host, uint32_t tag, void* stream);
+/* n standard normals and/or the raw Philox words they came from (block b = counter (b_lo, b_hi, step, tag)). */
+int vaek_rng_fill(vaek_ctx* ctx, float* normals, uint32_t* bits, int64_t n, uint64_t seed, uint32_t step, uint32_t tag,
+                  void* stream);
+/* Optional device ring buffer: every vaek_train_step also stores its loss at buf[(t - 1) % cap],
+ * t = Adam step (what the reference appends to vae_losses, vae.py:130, without a per-step copy). */
+int vaek_set_loss_history(vaek_ctx* ctx, float* buf, int64_t cap);
+
 /* ---- in-process kernel timing (bench.py's roofline leg) --------------------------------------- */
 /* Between begin and report every kernel the library launches for this context is bracketed by a
  * pair of hipEvents recorded on the launch stream (pool of max_records pairs, allocated here, so

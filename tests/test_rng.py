@@ -1,0 +1,104 @@
+"""Philox / Box-Muller: the NumPy oracle against Random123's published known answers (CPU), and the
+HIP generator (csrc/rng.hip) against that oracle + distributional checks (GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox as P
+
+# Random123 kat_vectors, philox4x32 with 10 rounds: counter[4] key[2] -> expected[4]
+KAT = [
+    ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+    ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+]
+
+
+@pytest.mark.parametrize("ctr,key,want", KAT)
+def test_philox_oracle_known_answers(ctr, key, want):
+    assert tuple(int(v) for v in P.philox4x32(ctr, key)) == want
+
+
+def test_box_muller_oracle_moments():
+    ctr = np.zeros((50000, 4), dtype=np.uint32); ctr[:, 0] = np.arange(50000)
+    n = P.normals_from_bits(P.philox4x32(ctr, (7, 9))).reshape(-1)
+    assert abs(n.mean()) < 0.01 and abs(n.std() - 1) < 0.01 and abs(((n - n.mean()) ** 4).mean() - 3) < 0.1
+
+
+@pytest.mark.gpu
+def test_device_philox_bits_and_normals_match_oracle():
+    from vae_training_amd.engine import Engine
+    eng = Engine(64, 12, 20)
+    n, seed, step, tag = 4099, 0x123456789ABCDEF, 17, 3
+    normals, bits = eng.rng_fill(n, seed, step, tag, bits=True)
+    nb = (n + 3) // 4
+    ctr = np.zeros((nb, 4), dtype=np.uint32); ctr[:, 0] = np.arange(nb); ctr[:, 2] = step; ctr[:, 3] = tag
+    want = P.philox4x32(ctr, (seed & 0xFFFFFFFF, seed >> 32))
+    assert np.array_equal(bits.cpu().numpy().view(np.uint32), want.reshape(-1)[:n])        # bit exact
+    assert np.max(np.abs(normals.cpu().numpy() - P.normals_from_bits(want).reshape(-1)[:n])) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["linear_gaussian", "sigmoid", "sphere"])
+def test_make_batch_reproduces_datasets_py(kind):
+    """Rows are a pure function of (seed, step, tag, global row): equal to the oracle's stream pushed through
+    the dataset formulas of datasets.py, independent of how rows are sharded."""
+    from vae_training_amd.datasets import LinearGaussianDataset, SigmoidDataset, SphereDataset
+    from vae_training_amd.engine import Engine
+    ds = {"linear_gaussian": lambda: LinearGaussianDataset(2, 3, 3, 9, var_added=0.04), "sigmoid": lambda: SigmoidDataset(69, 3, 3),
+          "sphere": lambda: SphereDataset(69, 3, 3)}[kind]()
+    D, L, rows, seed, step = ds.dimension, 5, 300, 99, 12
+    eng = Engine(rows, D, L, sigmoid_decoder=(kind == "sigmoid"))
+    k, A, dd, did, pad, var = ds.device_spec()
+    x, z1, z2 = eng.make_batch(k, A, dd, did, pad, var, rows, seed, step=step, tag=0)
+    xa, z1a, z2a = (t.cpu().numpy().astype(np.float64) for t in (x, z1, z2))
+    Ah = None if A is None else A.cpu().numpy().astype(np.float64)
+    for i in (0, 1, 157, 299):
+        nd = {"linear_gaussian": did + D, "sigmoid": dd, "sphere": dd}[kind]
+        n = P.sample_normals(seed, step, 0, i, nd)
+        if kind == "linear_gaussian":
+            want = np.concatenate([Ah.reshape(dd, did) @ n[:did], np.zeros(pad)]) + np.sqrt(var) * n[did:did + D]
+        elif kind == "sigmoid":
+            want = np.concatenate([n[:dd], [1 / (1 + np.exp(-(n[:dd] @ Ah)))], np.zeros(pad)])
+        else:
+            want = np.concatenate([n[:dd] / np.linalg.norm(n[:dd]), np.zeros(pad)])
+        assert np.max(np.abs(xa[i] - want)) < 5e-5, (kind, i)
+        z = P.sample_normals(seed, step, 0x40000000, i, L + D)           # model.py:227 column order
+        assert np.max(np.abs(np.concatenate([z1a[i], z2a[i]]) - z)) < 5e-5
+    # sharding: rows 100..199 generated alone equal rows 100..199 of the full batch, bit for bit
+    eng2 = Engine(100, D, L, sigmoid_decoder=(kind == "sigmoid"))
+    x2, z12, z22 = eng2.make_batch(k, A, dd, did, pad, var, 100, seed, step=step, tag=0, row0=100)
+    assert torch.equal(x2, x[100:200]) and torch.equal(z12, z1[100:200]) and torch.equal(z22, z2[100:200])
+    # a different step or tag gives a different batch; moments are right
+    x3, _, _ = eng.make_batch(k, A, dd, did, pad, var, rows, seed, step=step + 1, tag=0)
+    assert not torch.equal(x3, x)
+    big = Engine(65536, D, L, sigmoid_decoder=(kind == "sigmoid"))
+    xb, z1b, z2b = big.make_batch(k, A, dd, did, pad, var, 65536, seed, step=1)
+    for z in (z1b, z2b):
+        assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1) < 0.01
+    if kind == "sphere":
+        assert torch.allclose(xb[:, :dd].norm(dim=1), torch.ones(65536, device="cuda"), atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_graph_loop_equals_eager_steps(tmp_path):
+    """trainer.GraphLoop (hipGraph replay, device RNG, loss ring) == the same steps issued one by one."""
+    from vae_training_amd.run import get_dataset, parse_arguments
+    from vae_training_amd.trainer import GraphLoop
+    from vae_training_amd.vae import VAEModel
+
+    def build():
+        args = parse_arguments(["t", "--dataset", "linear_gaussian", "--padding_dim", "9", "-dd", "3", "-ds", "2"])
+        ds = get_dataset("linear_gaussian", 2, 9, 100, args)
+        return VAEModel(dirname=str(tmp_path), num_batches=10, num_epochs=1, batch_size=100, learning_rate=1e-3, layer_sizes="",
+                        encoder_layer_sizes="", state_dict=None, data_fn=None, epsilon=-1.0, tqdm=False, dataset=ds,
+                        latent_dimension=20, tunable_decoder_var=True, dataset_name="linear_gaussian")
+    a, b = build(), build()
+    la, lb = GraphLoop(a, steps_per_graph=8, seed=5), GraphLoop(b, steps_per_graph=8, seed=5)
+    la.run(30)                       # 2 eager warm-ups + 3 replays of 8 + 4 eager
+    for _ in range(30):
+        lb._one()
+    torch.cuda.synchronize()
+    assert a.optimizer.state.step == 30 == int(a.optimizer.state.step_dev.item()) == int(b.optimizer.state.step_dev.item())
+    assert torch.equal(a.model.flat, b.model.flat) and torch.equal(la.losses(), lb.losses())
+    assert la.losses().numel() == 30 and bool(torch.isfinite(la.losses()).all())

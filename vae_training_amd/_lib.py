@@ -58,6 +58,10 @@ SIGNATURES = {
     "vaek_comm_status": (C.c_int, [_vp, C.POINTER(_i32)]),
     "vaek_comm_destroy": (C.c_int, [_vp]),
     "vaek_comm_allreduce": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "vaek_make_batch": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _i32, _i64, C.c_uint64, _vp,
+                                  C.c_uint32, C.c_uint32, _vp]),
+    "vaek_rng_fill": (C.c_int, [_vp, _vp, _vp, _i64, C.c_uint64, C.c_uint32, C.c_uint32, _vp]),
+    "vaek_set_loss_history": (C.c_int, [_vp, _vp, _i64]),
     "vaek_profile_begin": (C.c_int, [_vp, _i32]),
     "vaek_profile_report": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
 }

@@ -157,6 +157,8 @@ static int generic_finalize(vaek_ctx* c, const float* params, float* grads, floa
     // Adam is fused into the finalize kernel only while epsilon_p, epsilon and the scalar sums all sit
     // in its block 0 (64 outputs): the loss lanes read epsilon_p, so its Adam writers must be behind the
     // same block-local barrier.  Wider latents take a separate Adam launch.
+    f.loss_hist = c->cfg.world == 1 ? c->loss_hist : nullptr; f.loss_hist_cap = c->loss_hist_cap;
+    if (!f.step_dev) f.loss_hist = nullptr;
     const bool fuse = params_rw != nullptr && c->L + 5 <= 64;
     if (!fuse) f.params_rw = nullptr;
     int rc = launch_finalize(f, st);

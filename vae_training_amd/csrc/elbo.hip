@@ -207,6 +207,7 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeArgs a) {
                                 // writers run after this barrier in block 0 or never touch those leaves)
     if (!live) return;
     a.grads[i] = g;
+    if (i == a.P && a.loss_hist && a.step_dev) a.loss_hist[(long long)(a.step_dev[0] - 1) % a.loss_hist_cap] = g;
     if (adam) {
         float bc1, bc2;
         adam_bias_corrections(tstep, bc1, bc2);

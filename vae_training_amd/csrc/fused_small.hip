@@ -394,6 +394,7 @@ struct FusedFinArgs {
     float* grads;
     float* params_rw; float* m; float* v; const int32_t* step_dev; float lr;
     CommDev comm;              // comm.world > 1: sum over ranks inside this kernel (epoch = Adam step)
+    float* loss_hist; long long loss_hist_cap;    // optional: loss of Adam step t -> loss_hist[(t-1) % cap]
 };
 
 __device__ __forceinline__ void adam_apply_f(float& p, float g, float& m, float& v, float lr, float bc1, float bc2) {
@@ -471,6 +472,7 @@ __global__ __launch_bounds__(1024) void fused_finalize_kernel(const FusedFinArgs
     if (!live) return;
     if (a.comm.world > 1) g = comm_exchange_sum(a.comm, (unsigned)a.step_dev[0], idx, g);   // xGMI, all ranks
     a.grads[idx] = g;
+    if (idx == a.P && a.loss_hist) a.loss_hist[(long long)(a.step_dev[0] - 1) % a.loss_hist_cap] = g;
     if (adam) {
         const float bc1 = -expm1f((float)tstep * -0.10536051565782628f);
         const float bc2 = -expm1f((float)tstep * -0.0010005003335835335f);
@@ -572,6 +574,7 @@ int fused_train_step(vaek_ctx* c, float* params, float* grads, float* m, float* 
     f.params_rw = apply_adam ? params : nullptr; f.m = m; f.v = v; f.step_dev = step_dev; f.lr = lr;
     f.comm = CommDev{};
     if (exchange) f.comm = comm_dev(c, 0);
+    f.loss_hist = (apply_adam && (exchange || c->cfg.world == 1)) ? c->loss_hist : nullptr; f.loss_hist_cap = c->loss_hist_cap;
     {
         ProfScope ps(apply_adam ? "fused_finalize_adam" : "fused_finalize", st);
         launch_k(ps, fused_finalize_kernel, dim3((unsigned)((c->P + kExtra + 63) / 64)), dim3(1024), 0, st, f);

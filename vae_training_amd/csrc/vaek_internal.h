@@ -100,6 +100,8 @@ struct vaek_ctx {
     vaek::Comm comm;
     vaek::Profiler prof;
     unsigned long long* dbg_stamps = nullptr;   // diagnostic builds (-DVAEK_STAMPS) only
+    float* loss_hist = nullptr;                 // optional device ring: loss of Adam step t -> [(t-1) % cap]
+    int64_t loss_hist_cap = 0;
 };
 
 namespace vaek {
@@ -140,6 +142,7 @@ struct FinalizeArgs {
     float* grads;             // P + 4
     // optional fused Adam (world == 1): params_rw != nullptr
     float* params_rw; float* m; float* v; const int32_t* step_dev; float lr;
+    float* loss_hist; long long loss_hist_cap;    // optional: loss of Adam step t -> loss_hist[(t-1) % cap]
 };
 int launch_finalize(const FinalizeArgs& a, hipStream_t st);
 int launch_adam(float* params, const float* grads, float* m, float* v, int64_t n, float lr, int step,

@@ -37,6 +37,10 @@ class DistributionDataset:
     def load(self, fn):
         pass
 
+    def device_spec(self):
+        """(kind, A, dd, did, pad, var_added) for libvaek's make_batch kernel (include/vaek.h)."""
+        raise NotImplementedError
+
     def _pad(self, body, size):
         if self.padding_dim == 0:
             return body.contiguous()
@@ -60,6 +64,9 @@ class SphereDataset(DistributionDataset):
         g = vrandom.normal(self.get_key(), (size, self.dim), self.device)
         samps = self._pad(g / g.norm(dim=1, keepdim=True), size)
         return (samps, None) if return_latents else samps
+
+    def device_spec(self):
+        return 2, None, self.dim, self.dim, self.padding_dim, 0.0
 
     def score_batch(self, batch):
         real, padding = batch[:, :self.dim], batch[:, self.dim:]
@@ -98,6 +105,9 @@ class LinearGaussianDataset(DistributionDataset):
             Y = Y + vrandom.normal(self.get_key(), (size, self.ndim), self.device) * math.sqrt(self.var_added)
         return (Y, None) if return_latents else Y
 
+    def device_spec(self):
+        return 0, self.A.contiguous(), self.dim, self.intrinsic_dim, self.padding_dim, float(self.var_added)
+
     def score_batch(self, batch):
         return {"Squared Norm of padding dimensions": batch[:, self.dim:].square().sum(dim=1).mean()}
 
@@ -134,6 +144,9 @@ class SigmoidDataset(DistributionDataset):
         Y[:, :self.dim] = z
         Y[:, self.dim] = torch.sigmoid(z @ self.A).squeeze(1)
         return (Y, None) if return_latents else Y
+
+    def device_spec(self):
+        return 1, self.A.reshape(-1).contiguous(), self.dim, 1, self.padding_dim, 0.0
 
     def score_batch(self, batch):
         codomain = (batch[:, :self.dim] @ self.A)

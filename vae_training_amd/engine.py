@@ -132,6 +132,32 @@ class Engine:
                                          float(eps), _ptr(x_hat), _ptr(mu), rows, _ptr(self.workspace), _stream()))
         return x_hat, mu
 
+    # ---- on-device inputs (K7) and the loss ring ------------------------------------------------
+    def make_batch(self, kind, A, dd, did, pad, var_added, rows, seed, step_dev=None, step=0, tag=0, row0=0,
+                   want_x=True, out=None):
+        """x[rows,D] (or None), z1[rows,L], z2[rows,D] drawn by libvaek's Philox kernel."""
+        if out is None:
+            x = torch.empty(rows, self.D, dtype=torch.float32, device=self.device) if want_x else None
+            z1 = torch.empty(rows, self.L, dtype=torch.float32, device=self.device)
+            z2 = torch.empty(rows, self.D, dtype=torch.float32, device=self.device)
+        else:
+            x, z1, z2 = out
+        _lib.check(self.lib.vaek_make_batch(self.h, int(kind), _ptr(A), int(dd), int(did), int(pad), float(var_added),
+                                            _ptr(x), _ptr(z1), _ptr(z2), int(rows), int(row0), int(seed) & (2**64 - 1),
+                                            _ptr(step_dev), int(step), int(tag), _stream()))
+        return x, z1, z2
+
+    def rng_fill(self, n, seed, step=0, tag=0, bits=False):
+        out_n = torch.empty(n, dtype=torch.float32, device=self.device)
+        out_u = torch.empty(n, dtype=torch.int32, device=self.device) if bits else None
+        _lib.check(self.lib.vaek_rng_fill(self.h, _ptr(out_n), _ptr(out_u), int(n), int(seed) & (2**64 - 1), int(step),
+                                          int(tag), _stream()))
+        return (out_n, out_u) if bits else out_n
+
+    def set_loss_history(self, buf):
+        self._loss_hist = buf                      # keep it alive
+        _lib.check(self.lib.vaek_set_loss_history(self.h, _ptr(buf), 0 if buf is None else buf.numel()))
+
     # ---- in-process kernel timing (bench.py) ------------------------------------------------
     def profile_begin(self, max_records=4096):
         _lib.check(self.lib.vaek_profile_begin(self.h, int(max_records)))

@@ -137,6 +137,8 @@ class GenerativeModel(Model):
                 it = trange(self.num_batches)
             except ImportError:
                 pass
+        if getattr(self, "fast_loop", False):
+            return self._train_distribution_fast()
         for self.batchnum in it:
             if self.batchnum % self.n_print == 0:
                 self.write_stats(self.compute_stats())
@@ -144,6 +146,26 @@ class GenerativeModel(Model):
                 self.plot_epoch()
                 self.save()
             self.train_one_batch(self.dataset.get_batch(self.batch_size))
+
+    def _train_distribution_fast(self):
+        """Same schedule (stats every n_print, plot+save every n_plot and at the last step), but the steps in
+        between run from a hipGraph with on-device batch generation (trainer.GraphLoop)."""
+        from .trainer import GraphLoop
+        loop = GraphLoop(self)
+        self._graph_loop = loop
+        events = sorted(set(list(range(0, self.num_batches, self.n_print)) + list(range(0, self.num_batches, self.n_plot))
+                            + [self.num_batches - 1]))
+        pos = 0
+        for ev in events:
+            loop.run(ev - pos)
+            pos = ev
+            self.batchnum = ev
+            if ev % self.n_print == 0:
+                self.write_stats(self.compute_stats())
+            if ev % self.n_plot == 0 or ev == self.num_batches - 1:
+                self.plot_epoch()
+                self.save()
+        loop.run(self.num_batches - pos)
 
     def save(self, final=False):
         data = self.model_save_data(final=final)

@@ -41,6 +41,8 @@ def build_parser():
     p.add_argument("-off", "--latent_off_dimension", type=int, default=1)
     p.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: current)")
     p.add_argument("--force_generic", action="store_true", help="layer-by-layer kernels even where a fused path exists")
+    p.add_argument("--fast_loop", action="store_true",
+                   help="run the steps between stats/plots from a hipGraph with on-device Philox batches (trainer.py)")
     return p
 
 
@@ -76,7 +78,7 @@ def get_model(args, dataset, output_dir):
                     epsilon=args.epsilon, tqdm=args.tqdm, latent_dimension=args.latent_dimension,
                     tunable_decoder_var=args.tunable_decoder_var, warm_start=args.warm_start,
                     dataset_name=args.dataset, latent_off_dimension=args.latent_off_dimension,
-                    force_generic=getattr(args, "force_generic", False))
+                    force_generic=getattr(args, "force_generic", False), fast_loop=getattr(args, "fast_loop", False))
 
 
 def main(args):

@@ -20,7 +20,7 @@ class VAEModel(GenerativeModel):
     def __init__(self, dirname, num_batches, num_epochs, batch_size, learning_rate, layer_sizes,
                  encoder_layer_sizes, state_dict, data_fn, epsilon, tqdm, dataset, latent_dimension,
                  tunable_decoder_var=False, warm_start=False, dataset_name=None, latent_off_dimension=0,
-                 exchange=None, global_batch=0, world=1, rank=0, force_generic=False):
+                 exchange=None, global_batch=0, world=1, rank=0, force_generic=False, fast_loop=False):
         super().__init__(dirname=dirname, num_batches=num_batches, num_epochs=num_epochs, batch_size=batch_size,
                          learning_rate=learning_rate, latent_distribution="gaussian",
                          latent_dimension=latent_dimension, dataset=dataset, state_dict=state_dict,
@@ -28,6 +28,7 @@ class VAEModel(GenerativeModel):
         if warm_start:
             raise NotImplementedError("-ws/--warm_start is out of scope (reference vae.py:62-107 relies on the "
                                       "removed jax.ops.index_update; no shipped experiment script uses it)")
+        self.fast_loop = fast_loop
         self.epsilon = epsilon
         self.current_epsilon = epsilon
         self.latent_dimension = latent_dimension
@@ -76,7 +77,10 @@ class VAEModel(GenerativeModel):
         return x_hat, z
 
     def model_save_data(self, final=False):
-        data = {"VAE Loss": self.vae_losses, "Decoder Variance": self.var_dec, "Encoder Variance": self.var_enc}
+        loop = getattr(self, "_graph_loop", None)
+        if loop is not None:                # fast loop: train losses live in the device ring, eval losses in the list
+            self.vae_losses_train = loop.losses()
+        data = {"VAE Loss": self.vae_losses if loop is None else list(self.vae_losses) + list(self.vae_losses_train), "Decoder Variance": self.var_dec, "Encoder Variance": self.var_enc}
         if final:
             data["Correlation Ratio"] = self.correlation_ratios       # always empty, as in the reference
         return data
