@@ -1,0 +1,56 @@
+"""-m gpu: the bf16 matrix-core Dense path (vaek_config.dtype = VAEK_BF16).  bf16 products carry 2^-9
+relative rounding per operand, so this path is NOT held to the 1e-5 ELBO contract (that is the f32
+path's, tests/test_gpu_parity.py); the tolerances below are its measured envelope against the float64
+oracle on the same inputs: loss 2e-3 relative, gradient 2e-2 of the leaf-set max-abs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import elbo_oracle as O
+from tests.gpu_util import dev, engine_for, host, random_problem, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("hidden,B", [((128,), 700), ((256, 128), 1000), ((192, 64, 192), 333)])
+@pytest.mark.parametrize("dataset", ["sphere", "sigmoid"])
+def test_bf16_dense_path_tracks_oracle(hidden, B, dataset):
+    D = 7 if dataset == "sigmoid" else 6
+    cfg = O.Config(D, 6, hidden, hidden, -3.0, True, dataset)
+    dk = dict(name=dataset, seed=69, dd=3, pad=3)
+    p, x, z1, z2 = random_problem(cfg, dk, B)
+    loss, g = O.loss_and_grad(cfg, p, x, z1, z2)
+    eng = engine_for(cfg, B, dtype="bf16")
+    assert not eng.fused
+    params = dev(O.flatten(cfg, p)); grads = eng.new_flat(eng.grad_len)
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    eng.grads_only(params, grads, step, dev(x), dev(z1), dev(z2))
+    got = host(grads)
+    assert abs(got[eng.P] - loss) <= 2e-3 * abs(loss), (got[eng.P], loss)
+    assert rel_err(got[:eng.P], O.flatten(cfg, g)) <= 2e-2
+    # and it is genuinely a different arithmetic from the f32 path (the bf16 kernels ran)
+    e32 = engine_for(cfg, B)
+    g32 = e32.new_flat(e32.grad_len)
+    e32.grads_only(params, g32, step, dev(x), dev(z1), dev(z2))
+    if len(hidden) >= 2:                       # a layer with both dims >= 64 exists -> the bf16 kernels ran
+        assert not torch.equal(g32, grads)
+    else:                                      # only skinny layers: they stay on the exact f32 kernels by design
+        assert torch.equal(g32, grads)
+    assert abs(host(g32)[eng.P] - loss) <= 1e-5 * abs(loss)
+
+
+def test_bf16_train_steps_reduce_loss():
+    cfg = O.Config(6, 6, (256, 256), (256, 256), -3.0, True, "sphere")
+    B, lr = 4096, 1e-3
+    _, sampler = O.make_dataset("sphere", 69, dd=3, pad=3)
+    rng = np.random.default_rng(0)
+    eng = engine_for(cfg, B, dtype="bf16")
+    p = O.init_params(cfg, seed=0)
+    params = dev(O.flatten(cfg, p)); grads = eng.new_flat(eng.grad_len); m = eng.new_flat(); v = eng.new_flat()
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    losses = []
+    for s in range(40):
+        z = rng.standard_normal((B, 12))
+        eng.train_step(params, grads, m, v, step, dev(sampler(rng, B)), dev(z[:, :6]), dev(z[:, 6:]), lr)
+        losses.append(float(grads[eng.P]))
+    assert np.isfinite(losses).all() and np.mean(losses[-5:]) < np.mean(losses[:5])

@@ -65,6 +65,11 @@ static int check_ws(const vaek_ctx* c, const void* ws) {
 template <typename T>
 static T* at(void* ws, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(ws) + off); }
 
+// dtype = VAEK_BF16 routes the WIDE layers (both dims >= 64) through the bf16 matrix-core kernels; skinny
+// input/output layers (D, L of a handful of features) stay on the exact f32 kernels -- they are
+// bandwidth-bound and carry the reparameterisation / ELBO inputs.
+static bool use_bf16(const vaek_ctx* c, int n_in, int n_out) { return c->cfg.dtype == VAEK_BF16 && n_in >= 64 && n_out >= 64; }
+
 // ---- forward through one Dense/relu stack; `reparam` fuses networks.py:73-74 into the last layer
 static int net_forward(vaek_ctx* c, const Net& net, const float* params, const float* in, void* ws, int rows,
                        bool reparam, const float* z1, hipStream_t st) {
@@ -75,11 +80,12 @@ static int net_forward(vaek_ctx* c, const Net& net, const float* params, const f
         const float* b = w + (int64_t)l.n_in * l.n_out;
         float* y = at<float>(ws, net.act_off[i]);
         int rc;
+        const bool h16 = use_bf16(c, l.n_in, l.n_out);
         if (reparam && i + 1 == net.layers.size())
-            rc = launch_dense_fwd_reparam(h, w, b, y, at<float>(ws, c->ws_samples), z1, params + c->off_epsp, rows,
-                                          l.n_in, l.n_out, st);
+            rc = (h16 ? launch_dense_fwd_reparam_bf16 : launch_dense_fwd_reparam)(h, w, b, y, at<float>(ws, c->ws_samples), z1,
+                                                                                  params + c->off_epsp, rows, l.n_in, l.n_out, st);
         else
-            rc = launch_dense_fwd(h, w, b, y, rows, l.n_in, l.n_out, l.relu, st);
+            rc = (h16 ? launch_dense_fwd_bf16 : launch_dense_fwd)(h, w, b, y, rows, l.n_in, l.n_out, l.relu, st);
         if (rc) return rc;
         h = y;
     }
@@ -98,16 +104,19 @@ static int net_backward(vaek_ctx* c, const Net& net, const float* params, const 
         const Layer& l = net.layers[i];
         const float* w = params + l.w_off;
         const float* h_in = i == 0 ? in : at<float>(ws, net.act_off[i - 1]);
-        int rc = launch_dense_bwd_dw(h_in, d, slabs + l.w_off, c->P, c->S, c->rows_per_split, c->B, l.n_in, l.n_out, st);
+        const bool h16 = use_bf16(c, l.n_in, l.n_out);
+        int rc = (h16 ? launch_dense_bwd_dw_bf16 : launch_dense_bwd_dw)(h_in, d, slabs + l.w_off, c->P, l.S, l.rows_per_split,
+                                                                        c->B, l.n_in, l.n_out, st);
         if (rc) return rc;
         if (i > 0) {
             float* dx = gb[tog];
             tog ^= 1;
-            rc = launch_dense_bwd_dx(d, w, h_in, dx, c->B, l.n_in, l.n_out, true, false, st);
+            rc = (h16 ? launch_dense_bwd_dx_bf16 : launch_dense_bwd_dx)(d, w, h_in, dx, c->B, l.n_in, l.n_out, true, false, st);
             if (rc) return rc;
             d = dx;
         } else if (dx_first) {
-            rc = launch_dense_bwd_dx(d, w, nullptr, dx_first, c->B, l.n_in, l.n_out, false, accumulate_first, st);
+            rc = (h16 ? launch_dense_bwd_dx_bf16 : launch_dense_bwd_dx)(d, w, nullptr, dx_first, c->B, l.n_in, l.n_out, false,
+                                                                        accumulate_first, st);
             if (rc) return rc;
         }
     }
@@ -148,6 +157,12 @@ static int generic_finalize(vaek_ctx* c, const float* params, float* grads, floa
                             const int32_t* step_dev, float lr, void* ws, hipStream_t st) {
     FinalizeArgs f{};
     f.slabs = at<float>(ws, c->ws_slabs); f.slab_stride = c->P; f.S = c->S;
+    f.nseg = 0;
+    for (const Net* net : {&c->enc, &c->dec, &c->sig})
+        for (const auto& l : net->layers) {
+            f.seg_end[f.nseg] = (int)(l.w_off + (int64_t)(l.n_in + 1) * l.n_out);
+            f.seg_S[f.nseg++] = l.S;
+        }
     f.epart = at<float>(ws, c->ws_epart); f.rpart = at<float>(ws, c->ws_rpart); f.Se = c->Se;
     f.P = c->P; f.off_epsp = c->off_epsp; f.off_eps = c->off_eps; f.L = c->L; f.D = c->D;
     f.params = params; f.eps_cli = c->cfg.eps_cli;
@@ -230,14 +245,20 @@ int vaek_ctx_create(const vaek_config* cfg, vaek_ctx** out) {
     }
     // batch splits: dW|db GEMM slabs sized so that (tiles x S) fills the chip; elementwise
     // partials one per <= 1024 row-blocks
-    int max_tiles = 1;
-    auto tiles = [&](const Net& n) {
-        for (auto& l : n.layers) max_tiles = std::max(max_tiles, ((l.n_in + 1 + 63) / 64) * ((l.n_out + 63) / 64));
+    c->S = 1; c->rows_per_split = c->B;
+    auto splits = [&](Net& n) {
+        for (auto& l : n.layers) {
+            const int tiles = ((l.n_in + 1 + 63) / 64) * ((l.n_out + 63) / 64);
+            const int s_target = std::min(256, std::max(4, 1024 / tiles));
+            l.rows_per_split = std::max(64, (int)align_up((size_t)(c->B + s_target - 1) / s_target, 64));
+            l.S = (c->B + l.rows_per_split - 1) / l.rows_per_split;
+            if (l.S > c->S) { c->S = l.S; c->rows_per_split = l.rows_per_split; }
+        }
     };
-    tiles(c->enc); tiles(c->dec); tiles(c->sig);
-    int s_target = std::min(256, std::max(4, 1024 / max_tiles));
-    c->rows_per_split = std::max(64, (int)align_up((size_t)(c->B + s_target - 1) / s_target, 64));
-    c->S = (c->B + c->rows_per_split - 1) / c->rows_per_split;
+    splits(c->enc); splits(c->dec); splits(c->sig);
+    if (c->enc.layers.size() + c->dec.layers.size() + c->sig.layers.size() > 32) {
+        set_error("too many layers"); delete c; return VAEK_ERR_INVALID;
+    }
     c->rows_per_esplit = std::max(64, (int)align_up((size_t)(c->B + 1023) / 1024, 64));
     c->Se = (c->B + c->rows_per_esplit - 1) / c->rows_per_esplit;
 

@@ -159,8 +159,10 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeArgs a) {
             const float* r = a.rpart + (i - a.off_epsp);
             for (int s = q; s < a.Se; s += FINQ) acc += r[(long long)s * a.L];
         } else {
+            int S = a.S;                               // slabs written for this output's layer
+            for (int k = a.nseg - 1; k >= 0; --k) if (i < a.seg_end[k]) S = a.seg_S[k];
             const float* p = a.slabs + i;
-            for (int s = q; s < a.S; s += FINQ) acc += p[(long long)s * a.slab_stride];
+            for (int s = q; s < S; s += FINQ) acc += p[(long long)s * a.slab_stride];
         }
     } else if (i == a.P || i == a.P + 1) {
         for (int s = q; s < a.Se; s += FINQ) acc += a.epart[s * 4 + (int)(i - a.P)];      // sum mse terms, sum mu^2

@@ -34,6 +34,7 @@ struct Layer {
     int n_in, n_out;
     int64_t w_off;    // kernel offset in the flat buffers; bias follows at w_off + n_in*n_out
     bool relu;        // relu after this layer (every layer but the last, networks.py:35-39)
+    int S, rows_per_split;   // batch split of this layer's dW|db GEMM (skinny layers get more, smaller splits)
 };
 
 struct Net {
@@ -118,6 +119,16 @@ int launch_dense_bwd_dx(const float* dy, const float* w, const float* x_post, fl
 int launch_dense_bwd_dw(const float* x, const float* dy, float* slab0, int64_t slab_stride, int S,
                         int rows_per_split, int rows, int n_in, int n_out, hipStream_t st);
 
+// ---- gemm_bf16.hip: the same four launchers with bf16 matrix-core arithmetic (f32 storage) -----------
+int launch_dense_fwd_bf16(const float* x, const float* w, const float* b, float* y, int rows, int n_in, int n_out,
+                          bool relu, hipStream_t st);
+int launch_dense_fwd_reparam_bf16(const float* x, const float* w, const float* b, float* mu, float* samples,
+                                  const float* z1, const float* lv, int rows, int n_in, int n_out, hipStream_t st);
+int launch_dense_bwd_dx_bf16(const float* dy, const float* w, const float* x_post, float* dx, int rows, int n_in,
+                             int n_out, bool relu, bool accumulate, hipStream_t st);
+int launch_dense_bwd_dw_bf16(const float* x, const float* dy, float* slab0, int64_t slab_stride, int S, int rows_per_split,
+                             int rows, int n_in, int n_out, hipStream_t st);
+
 // ---- elbo.hip -----------------------------------------------------------------------------
 struct ElboArgs {
     const float* x; const float* y_lin; const float* y_sig; const float* z2; const float* mu;
@@ -134,7 +145,8 @@ int launch_elbo(const ElboArgs& a, hipStream_t st);
 int launch_reparam_bwd(float* dsamp, const float* mu, const float* z1, float* partial,
                        int rows, int L, int S, int rows_per_split, float inv_bt, hipStream_t st);
 struct FinalizeArgs {
-    const float* slabs; int64_t slab_stride; int S;   // dW|db partials in flat-gradient layout
+    const float* slabs; int64_t slab_stride; int S;   // dW|db partials in flat-gradient layout (S = max over layers)
+    int nseg; int seg_end[32]; int seg_S[32];          // per layer: flat index one past its [kernel|bias], its slab count
     const float* epart; const float* rpart; int Se;   // elbo partials [Se][4], reparam partials [Se][L]
     int64_t P, off_epsp, off_eps; int L, D;
     const float* params;      // for logvar_e / epsilon
