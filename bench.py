@@ -266,12 +266,12 @@ def main():
             per_step = rep[dom]["count"] / args.steps            # launches of the dominant kernel per step
             P = eng.P
             if flops_per_sample(w) / (4.0 * (2 * D + L)) > 300.0:   # above the f32/bf16 ridge: MFMA-bound (C3)
-                # the layer-by-layer path launches the dominant GEMM kernel once per wide layer: price one
-                # launch with its share of the step's flops
-                alg = B_local * flops_per_sample(w) / max(1.0, per_step) * (rep[dom]["total_ms"] / sum(
-                    r["total_ms"] for k, r in rep.items() if k.startswith("gemm"))) * per_step
+                # layer-by-layer path: the Dense kernels run once per layer; price the step's flops against the
+                # time of all Dense launches of a step (kernel_avg_us stays the dominant kernel's own average)
+                alg = B_local * flops_per_sample(w)
+                gemm_s = sum(r["total_ms"] for k, r in rep.items() if k.startswith("gemm")) / args.steps * 1e-3
                 peak, unit, bound = (2500.0 if args.dtype == "bf16" else 157.3), "TFLOP/s", "mfma"
-                achieved = alg / avg_s / 1e12
+                achieved = alg / gemm_s / 1e12
             else:
                 alg = B_local * 4 * (2 * D + L)
                 peak, unit, bound = 8000.0, "GB/s", "hbm"
