@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--force-generic", action="store_true", help="layer-by-layer kernels even where a fused path exists")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a ONE-GPU box: every rank uses cuda:0 and the process group is gloo")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="Dense GEMM arithmetic (bf16: wide layers on bf16 MFMA)")
     ap.add_argument("--graph", type=int, default=-1,
                     help="steps captured per hipGraph (0 = eager launches; -1 = auto: nbuf-multiple near 20, single GPU only)")
@@ -165,12 +167,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py: no MI355X visible; the HIP path has no CPU fallback")
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from vae_training_amd.engine import Engine
     from vae_training_amd.parallel import GradExchange
@@ -244,7 +251,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_one_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = float(grads[eng.P].item())

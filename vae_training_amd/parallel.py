@@ -100,8 +100,13 @@ class GradExchange:
         return bool(t.value)
 
     def all_reduce(self, grads: torch.Tensor):
-        """SUM over ranks, in place (RCCL / gloo)."""
+        """SUM over ranks, in place (RCCL; gloo for CPU tensors and one-GPU rehearsals)."""
         if self.world == 1:
+            return grads
+        if grads.is_cuda and self.dist.get_backend() == "gloo":
+            host = grads.cpu()
+            self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM)
+            grads.copy_(host)
             return grads
         self.dist.all_reduce(grads, op=self.dist.ReduceOp.SUM)
         return grads
