@@ -234,6 +234,7 @@ def main():
                 for i in range(gsteps):
                     one_step(i)
         torch.cuda.current_stream().wait_stream(side)
+        fence()                             # ranks leave capture at different times: line them up first
         graph.replay()                      # one untimed replay (graph upload)
 
     def run_steps(n):

@@ -9,7 +9,7 @@
 //      bit-identical, its own contribution included since it is read back from its own slot).
 // A rank can run at most one epoch ahead of a peer (it needs that peer's granule to finish an epoch),
 // so two banks by epoch parity are enough.  Spins are bounded; on give-up the status word is set and
-// the host sees it -- nothing can hang the GPU.
+// the host sees it (vaek_comm_status) -- nothing can hang the GPU for good.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -17,7 +17,8 @@
 namespace vaek {
 
 constexpr int kMaxWorld = 8;
-constexpr unsigned kSpinLimit = 4000000u;     // x ~50 ns: gives up after ~0.2 s
+constexpr unsigned kSpinLimit = 1u << 27;      // x (load + s_sleep 8, >= ~0.2 us): gives up after ~30 s -- ranks of a job
+                                               // can be seconds apart at start-up (graph capture, first launches)
 
 struct CommDev {
     unsigned long long* peer[kMaxWorld];      // peer[r] = rank r's granule region (peer[rank] = local)
@@ -39,7 +40,7 @@ __device__ __forceinline__ float comm_exchange_sum(const CommDev& c, unsigned ep
             g = __hip_atomic_load(own + (long long)r * c.ng, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if ((unsigned)(g >> 32) == epoch) break;
             if (++spins > kSpinLimit) { __hip_atomic_store(c.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(8);
         }
         sum += __uint_as_float((unsigned)g);
     }
