@@ -1,0 +1,28 @@
+# Diagnostic: metric kernel with everything but dispatch + loads + partial-row store removed (-DVAEK_ABLATE).
+set -e
+cd $(dirname $0)/../vae_training_amd/csrc
+F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -DVAEK_FUSED_ONLY_M"
+for f in api gemm_f32 gemm_bf16 elbo fused_small comm rng; do /opt/rocm/bin/hipcc $F -c $f.hip -o /tmp/ab_$f.o; done
+/opt/rocm/bin/hipcc $F -DVAEK_ABLATE=${ABL:-1} -c fused_mfma.hip -o /tmp/ab_fused_mfma.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libvaek_ablate.so /tmp/ab_api.o /tmp/ab_gemm_f32.o /tmp/ab_gemm_bf16.o /tmp/ab_elbo.o /tmp/ab_fused_small.o /tmp/ab_fused_mfma.o /tmp/ab_comm.o /tmp/ab_rng.o
+cd ../..
+python3 - <<'PY'
+import os, sys
+sys.path.insert(0, os.getcwd())
+from vae_training_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libvaek_ablate.so")
+import torch, bench
+from vae_training_amd.engine import Engine
+w = bench.WORKLOADS["M"]; B = w["batch"]
+for waves in (4,):
+    eng = Engine(B, 12, 20, (), (), -1.0, True, False)
+    params = bench.init_params_flat(eng); grads = eng.new_flat(eng.grad_len); m = eng.new_flat(); v = eng.new_flat()
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    batches = bench.make_batches(w, B, eng.device, 4, 1)
+    for i in range(20): eng.grads_only(params, grads, step, *batches[i % 4])
+    eng.profile_begin(4096)
+    for i in range(200): eng.grads_only(params, grads, step, *batches[i % 4])
+    torch.cuda.synchronize()
+    rep = eng.profile_report()
+    print("ablated (loads + store only), waves", waves, {k: round(r["total_ms"] / r["count"] * 1e3, 2) for k, r in rep.items()})
+PY

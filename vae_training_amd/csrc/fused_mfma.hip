@@ -140,6 +140,22 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
             }
         }
     };
+#if defined(VAEK_ABLATE) && VAEK_ABLATE == 2   // diagnostic (tools/ablate.sh): the same bytes as wide, fully coalesced 16-byte loads
+    {
+        const long long s0 = (long long)blockIdx.x * G::TILE + wave * 64;      // this wave's first sample
+        const float4* px = reinterpret_cast<const float4*>(a.x + s0 * D);
+        const float4* pz2 = reinterpret_cast<const float4*>(a.z2 + s0 * D);
+        const float4* pz1 = reinterpret_cast<const float4*>(a.z1 + s0 * L);
+        float sink = 0.f;
+        for (int i = lane; i < 64 * D / 4; i += 64) { const float4 u = px[i], w2 = pz2[i]; sink += u.x + u.y + u.z + u.w + w2.x + w2.y + w2.z + w2.w; }
+        for (int i = lane; i < 64 * L / 4; i += 64) { const float4 u = pz1[i]; sink += u.x + u.y + u.z + u.w; }
+        sink += params[t % a.P];
+        float* outp = a.partials + (long long)blockIdx.x * a.pstride;
+        for (int idx = t; idx < a.P + kExtra; idx += 256) outp[idx] = sink;
+        if (blockIdx.x == 0 && t == 0 && a.step_dev) a.step_dev[0] += 1;
+        return;
+    }
+#endif
     load_inputs(blockIdx.x);
 
     // ---- weights as MFMA A operands (lane = output row ai, k group akg), zero outside [D, L] -------
@@ -210,6 +226,20 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
     float s_mse = 0.f, s_deps = 0.f, s_musq = 0.f;
     VAEK_MSTAMP(0);
 
+#ifdef VAEK_ABLATE   // diagnostic (tools/ablate.sh): what do dispatch + the input/weight loads + the partial-row store cost?
+    {
+        float sink = wmu[0][0][0] + wy[0][0][0] + wg[0][0][0] + c_be[0][0] + c_sd[0][0] + c_bd[0][0] + eps;
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sink += xv[s][0][r] + z2v[s][0][r] + z1v[s][0][r] + z1v[s][NLB - 1][r];
+        }
+        float* outp = a.partials + (long long)blockIdx.x * a.pstride;
+        for (int idx = t; idx < a.P + kExtra; idx += 256) outp[idx] = sink;
+        if (blockIdx.x == 0 && t == 0 && a.step_dev) a.step_dev[0] += 1;
+        return;
+    }
+#endif
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         if (tile != (int)blockIdx.x) load_inputs(tile);
         VAEK_MSTAMP(1);
