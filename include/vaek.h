@@ -176,7 +176,8 @@ int vaek_comm_status(vaek_ctx* ctx, int32_t* timed_out);
  * of model.py:225-228 split as vae.py:127-128 does (z1[rows,L], z2[rows,D]).  Row i of the call draws
  * from counter (row0 + i, block, step, tag) under key `seed`: reproducible, shardable by rows, and
  * graph-replayable when `step_dev` (the device Adam step counter) is given instead of step_host.
- * x may be NULL (latents only).  dd, did <= 16; tag < 2^30. */
+ * x may be NULL (latents only); z1 and z2 may both be NULL (dataset batch only, any D).  dd, did <= 16;
+ * tag < 2^30. */
 int vaek_make_batch(vaek_ctx* ctx, int32_t kind, const float* A, int32_t dd, int32_t did, int32_t pad, float var_added,
                     float* x, float* z1, float* z2, int32_t rows, int64_t row0, uint64_t seed,
                     const int32_t* step_dev, uint32_t step_host, uint32_t tag, void* stream);

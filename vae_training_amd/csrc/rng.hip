@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void make_batch_kernel(const BatchArgs a) {
             for (int d = a.dd; d < a.D; ++d) x[d] = 0.f;
         }
     }
+    if (!a.z1) return;
     // latent draw of model.py:227 in its column order: z[:, :L] = z1, z[:, L:] = z2  (vae.py:127-128)
     s.tag = a.tag + 0x40000000u; s.q = 0; s.have = 0;
     float* z1 = a.z1 + (long long)i * a.L;
@@ -109,16 +110,16 @@ extern "C" {
 int vaek_make_batch(vaek_ctx* ctx, int32_t kind, const float* A, int32_t dd, int32_t did, int32_t pad, float var_added,
                     float* x, float* z1, float* z2, int32_t rows, int64_t row0, uint64_t seed, const int32_t* step_dev,
                     uint32_t step_host, uint32_t tag, void* stream) {
-    if (!ctx || !z1 || !z2 || rows <= 0 || kind < 0 || kind > 2 || dd <= 0 || dd > 16 || did > 16 || pad < 0 ||
+    if (!ctx || (!z1) != (!z2) || (!x && !z1) || rows <= 0 || kind < 0 || kind > 2 || dd <= 0 || dd > 16 || did > 16 || pad < 0 ||
         (kind != 2 && x && !A) || tag >= 0x40000000u) {
         set_error("vaek_make_batch: invalid argument");
         return VAEK_ERR_INVALID;
     }
     const int D = dd + pad + (kind == 1 ? 1 : 0);
-    if (D != ctx->D) { set_error("vaek_make_batch: dataset dimension %d != context data_dim %d", D, ctx->D); return VAEK_ERR_INVALID; }
+    if (z1 && D != ctx->D) { set_error("vaek_make_batch: dataset dimension %d != context data_dim %d", D, ctx->D); return VAEK_ERR_INVALID; }
     BatchArgs a{};
     a.kind = kind; a.A = A; a.dd = dd; a.did = did; a.pad = pad; a.noise_std = var_added > 0.f ? sqrtf(var_added) : 0.f;
-    a.x = x; a.z1 = z1; a.z2 = z2; a.rows = rows; a.row0 = row0; a.D = ctx->D; a.L = ctx->L;
+    a.x = x; a.z1 = z1; a.z2 = z2; a.rows = rows; a.row0 = row0; a.D = D; a.L = ctx->L;
     a.seed = seed; a.step_dev = step_dev; a.step_host = step_host; a.tag = tag;
     g_prof = &ctx->prof;
     {

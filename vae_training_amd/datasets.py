@@ -27,6 +27,23 @@ class DistributionDataset:
         self.key, key = vrandom.split(self.key)
         return key
 
+    # ---- on a GPU, batches come from libvaek's Philox kernel (csrc/rng.hip): one launch, counter-based --
+    _draws = 0
+
+    def _device_batch(self, size):
+        """x[size, ndim] from vaek_make_batch (kind/A/dd/did/pad of device_spec), or None on a CPU-only host."""
+        if self.device.type != "cuda":
+            return None
+        from .engine import Engine
+        eng = getattr(self, "_util_engine", None)
+        if eng is None:
+            eng = self._util_engine = Engine(1, self.ndim, 1, device=self.device.index)   # carries no model: x-only draws
+        kind, A, dd, did, pad, var = self.device_spec()
+        self._draws += 1
+        x, _, _ = eng.make_batch(kind, A, dd, did, pad, var, size, seed=self.key[0] ^ self.key[1], step=self._draws, tag=1,
+                                 want_z=False)
+        return x
+
     @property
     def dimension(self):
         return int(math.prod(self.shape))
@@ -61,8 +78,10 @@ class SphereDataset(DistributionDataset):
         return (self.ndim,)
 
     def get_batch(self, size, return_latents=False):
-        g = vrandom.normal(self.get_key(), (size, self.dim), self.device)
-        samps = self._pad(g / g.norm(dim=1, keepdim=True), size)
+        samps = self._device_batch(size)
+        if samps is None:
+            g = vrandom.normal(self.get_key(), (size, self.dim), self.device)
+            samps = self._pad(g / g.norm(dim=1, keepdim=True), size)
         return (samps, None) if return_latents else samps
 
     def device_spec(self):
@@ -99,10 +118,12 @@ class LinearGaussianDataset(DistributionDataset):
         return (self.ndim,)
 
     def get_batch(self, size, return_latents=False):
-        X = vrandom.normal(self.get_key(), (size, self.intrinsic_dim), self.device)
-        Y = self._pad(X @ self.A.T, size)
-        if self.var_added > 0:
-            Y = Y + vrandom.normal(self.get_key(), (size, self.ndim), self.device) * math.sqrt(self.var_added)
+        Y = self._device_batch(size)
+        if Y is None:
+            X = vrandom.normal(self.get_key(), (size, self.intrinsic_dim), self.device)
+            Y = self._pad(X @ self.A.T, size)
+            if self.var_added > 0:
+                Y = Y + vrandom.normal(self.get_key(), (size, self.ndim), self.device) * math.sqrt(self.var_added)
         return (Y, None) if return_latents else Y
 
     def device_spec(self):
@@ -139,10 +160,12 @@ class SigmoidDataset(DistributionDataset):
         return (self.ndim,)
 
     def get_batch(self, size, return_latents=False):
-        z = vrandom.normal(self.get_key(), (size, self.dim), self.device)
-        Y = torch.zeros(size, self.ndim, dtype=torch.float32, device=self.device)
-        Y[:, :self.dim] = z
-        Y[:, self.dim] = torch.sigmoid(z @ self.A).squeeze(1)
+        Y = self._device_batch(size)
+        if Y is None:
+            z = vrandom.normal(self.get_key(), (size, self.dim), self.device)
+            Y = torch.zeros(size, self.ndim, dtype=torch.float32, device=self.device)
+            Y[:, :self.dim] = z
+            Y[:, self.dim] = torch.sigmoid(z @ self.A).squeeze(1)
         return (Y, None) if return_latents else Y
 
     def device_spec(self):

@@ -134,12 +134,13 @@ class Engine:
 
     # ---- on-device inputs (K7) and the loss ring ------------------------------------------------
     def make_batch(self, kind, A, dd, did, pad, var_added, rows, seed, step_dev=None, step=0, tag=0, row0=0,
-                   want_x=True, out=None):
+                   want_x=True, want_z=True, out=None):
         """x[rows,D] (or None), z1[rows,L], z2[rows,D] drawn by libvaek's Philox kernel."""
         if out is None:
-            x = torch.empty(rows, self.D, dtype=torch.float32, device=self.device) if want_x else None
-            z1 = torch.empty(rows, self.L, dtype=torch.float32, device=self.device)
-            z2 = torch.empty(rows, self.D, dtype=torch.float32, device=self.device)
+            Dx = dd + pad + (1 if kind == 1 else 0)
+            x = torch.empty(rows, Dx, dtype=torch.float32, device=self.device) if want_x else None
+            z1 = torch.empty(rows, self.L, dtype=torch.float32, device=self.device) if want_z else None
+            z2 = torch.empty(rows, self.D, dtype=torch.float32, device=self.device) if want_z else None
         else:
             x, z1, z2 = out
         _lib.check(self.lib.vaek_make_batch(self.h, int(kind), _ptr(A), int(dd), int(did), int(pad), float(var_added),

@@ -50,12 +50,25 @@ class VAEModel(GenerativeModel):
         if self.state_dict is not None:
             self.load()
 
+    def _latent_pair(self, key, batch_size):
+        """z1[B,L], z2[B,D] of model.py:227 / vae.py:127-128 as two contiguous tensors from ONE Philox launch
+        (csrc/rng.hip); sample_latent() below still returns the reference's single (B, L+D) array."""
+        eng = self.model.module.engine(batch_size, self.optimizer.global_batch)
+        self._latent_draws = getattr(self, "_latent_draws", 0) + 1
+        _, z1, z2 = eng.make_batch(0, None, 1, 1, eng.D - 1, 0.0, batch_size, seed=key[0] ^ key[1], step=self._latent_draws,
+                                   tag=2, want_x=False)
+        return z1, z2
+
+    def sample_latent(self, key, batch_size):
+        if self.dataset.device.type != "cuda":
+            return super().sample_latent(key, batch_size)
+        z1, z2 = self._latent_pair(key, batch_size)
+        return torch.cat([z1, z2], dim=1)
+
     def train_one_batch(self, batch):
         batch = batch.reshape(batch.shape[0], -1)
         latent_batch_key, self.key = vrandom.split(self.key)
-        z = self.sample_latent(latent_batch_key, self.batch_size)
-        z1 = z[..., :self.latent_dimension].contiguous()
-        z2 = z[..., self.latent_dimension:].contiguous()
+        z1, z2 = self._latent_pair(latent_batch_key, self.batch_size)
         self.optimizer, self.model, vae_loss = VAE.train_step(self.optimizer, batch, z1, z2, self.epsilon)
         self.vae_losses.append(vae_loss)
 
