@@ -295,6 +295,38 @@ def main():
                         "step_kernels_us": {k: r["total_ms"] / args.steps * 1e3 for k, r in rep.items()},
                         "param_bytes_per_step": 32 * P}
 
+    # ---- auxiliary (never `value`): the same step with FRESH inputs drawn on the device every step, as the
+    # reference's loop does (dataset.get_batch + sample_latent, model.py:221 / vae.py:125-128): one Philox
+    # kernel (vaek_make_batch) in front of the two train-step kernels, all inside the hipGraph
+    fresh = None
+    if world == 1 and graph is not None and w["dataset"] == "linear_gaussian":
+        A = torch.randn(w["dd"], w["did"], generator=torch.Generator().manual_seed(2)).to(device).contiguous()
+        xg, z1g, z2g = (torch.empty_like(t) for t in batches[0])
+
+        def fresh_step():
+            eng.make_batch(0, A, w["dd"], w["did"], w["pad"], 0.0, B_local, seed=7, step_dev=step_dev, tag=0, out=(xg, z1g, z2g))
+            eng.train_step(params, grads, m, v, step_dev, xg, z1g, z2g, lr)
+        for _ in range(3):
+            fresh_step()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, stream=side):
+                for _ in range(gsteps):
+                    fresh_step()
+        torch.cuda.current_stream().wait_stream(side)
+        g2.replay(); torch.cuda.synchronize()
+        nrep = max(1, args.steps // gsteps)
+        t1 = time.perf_counter()
+        for _ in range(nrep):
+            g2.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        fresh = {"samples_per_s": B_local * nrep * gsteps / dt, "us_per_step": dt / (nrep * gsteps) * 1e6,
+                 "note": "inputs generated on the device each step (Philox kernel) instead of pre-resident batches"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(w, B_local, args.cpu_seconds)
@@ -311,7 +343,7 @@ def main():
                        "parallelism": f"dp{world}", "grad_exchange": (exch.mode if exch else "none"),
                        "launch": (f"hipGraph x{gsteps} steps" if graph is not None else "eager"),
                        "final_loss": loss},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "fresh_inputs_each_step": fresh,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -47,3 +47,9 @@ def sample_normals(seed, step, tag, sample_index, n):
     ctr[:, 3] = np.uint32(tag)
     key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
     return normals_from_bits(philox4x32(ctr, key)).reshape(-1)[:n]
+
+
+def noise_block_offset(did):
+    """Dataset noise normals (linear_gaussian var_added > 0) start at Philox block ceil(did / 4) of the row's
+    dataset stream, one block per 4 data dims -- exactly as csrc/rng.hip draws them."""
+    return (did + 3) // 4

@@ -54,10 +54,10 @@ def test_make_batch_reproduces_datasets_py(kind):
     xa, z1a, z2a = (t.cpu().numpy().astype(np.float64) for t in (x, z1, z2))
     Ah = None if A is None else A.cpu().numpy().astype(np.float64)
     for i in (0, 1, 157, 299):
-        nd = {"linear_gaussian": did + D, "sigmoid": dd, "sphere": dd}[kind]
-        n = P.sample_normals(seed, step, 0, i, nd)
+        q0 = P.noise_block_offset(did)
+        n = P.sample_normals(seed, step, 0, i, 4 * q0 + D)
         if kind == "linear_gaussian":
-            want = np.concatenate([Ah.reshape(dd, did) @ n[:did], np.zeros(pad)]) + np.sqrt(var) * n[did:did + D]
+            want = np.concatenate([Ah.reshape(dd, did) @ n[:did], np.zeros(pad)]) + np.sqrt(var) * n[4 * q0:4 * q0 + D]
         elif kind == "sigmoid":
             want = np.concatenate([n[:dd], [1 / (1 + np.exp(-(n[:dd] @ Ah)))], np.zeros(pad)])
         else:

@@ -47,44 +47,86 @@ struct BatchArgs {
     unsigned long long seed; const int32_t* step_dev; unsigned step_host, tag;
 };
 
+// Work items: [0, rows) = one dataset row each (x: a handful of normals, row written as one contiguous
+// run); [rows, rows + rows*NZB) = one Philox block (4 normals) of one row's latent stream each, so that
+// consecutive lanes store consecutive 16-byte pieces of z1 / z2 -- the 11.5 MB of a 65 536-row batch
+// leave as coalesced stores instead of 44 scattered dwords per thread.
 __global__ __launch_bounds__(256) void make_batch_kernel(const BatchArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.rows) return;
-    NormalStream s;
-    s.key = make_uint2((unsigned)a.seed, (unsigned)(a.seed >> 32));
-    s.row = (unsigned)(a.row0 + i); s.step = a.step_dev ? (unsigned)a.step_dev[0] : a.step_host; s.tag = a.tag; s.q = 0; s.have = 0;
-    if (a.x) {
+    const long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint2 key = make_uint2((unsigned)a.seed, (unsigned)(a.seed >> 32));
+    const unsigned step = a.step_dev ? (unsigned)a.step_dev[0] : a.step_host;
+    const long long nx = a.x ? a.rows : 0;
+    if (item < nx) {
+        const int i = (int)item;
+        // up to 16 normals of the row's dataset stream, kept in registers: every index below is static
+        // (a runtime-indexed array would live in scratch memory)
+        const int nn = a.kind == 0 ? a.did : a.dd;
+        float nrm[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float n4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (4 * q < nn) normals4(philox4x32_10(make_uint4((unsigned)(a.row0 + i), (unsigned)q, step, a.tag), key), n4);
+            nrm[4 * q] = n4[0]; nrm[4 * q + 1] = n4[1]; nrm[4 * q + 2] = n4[2]; nrm[4 * q + 3] = n4[3];
+        }
         float* x = a.x + (long long)i * a.D;
         if (a.kind == 0) {                                       // Y = (A X^T)^T, zero padding, optional noise
-            float lat[16];
-            for (int k = 0; k < a.did; ++k) lat[k] = s.next();
             for (int d = 0; d < a.dd; ++d) {
                 float v = 0.f;
-                for (int k = 0; k < a.did; ++k) v = fmaf(a.A[d * a.did + k], lat[k], v);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) if (k < a.did) v = fmaf(a.A[d * a.did + k], nrm[k], v);
                 x[d] = v;
             }
             for (int d = a.dd; d < a.D; ++d) x[d] = 0.f;
-            if (a.noise_std > 0.f) for (int d = 0; d < a.D; ++d) x[d] += a.noise_std * s.next();
+            if (a.noise_std > 0.f) {                             // noise normals: blocks (did+3)/4 .. of the same stream
+                const int q0 = (a.did + 3) / 4;
+                for (int d0 = 0; d0 < a.D; d0 += 4) {
+                    float n4[4];
+                    normals4(philox4x32_10(make_uint4((unsigned)(a.row0 + i), (unsigned)(q0 + d0 / 4), step, a.tag), key), n4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (d0 + k < a.D) x[d0 + k] += a.noise_std * n4[k];
+                }
+            }
         } else if (a.kind == 1) {                                // [z, sigmoid(z.a), 0...]
             float dot = 0.f;
-            for (int d = 0; d < a.dd; ++d) { const float v = s.next(); x[d] = v; dot = fmaf(v, a.A[d], dot); }
+#pragma unroll
+            for (int d = 0; d < 16; ++d) if (d < a.dd) { x[d] = nrm[d]; dot = fmaf(nrm[d], a.A[d], dot); }
             x[a.dd] = 1.f / (1.f + expf(-dot));
             for (int d = a.dd + 1; d < a.D; ++d) x[d] = 0.f;
         } else {                                                 // g / |g|, zero padding
-            float g[16], nn = 0.f;
-            for (int d = 0; d < a.dd; ++d) { g[d] = s.next(); nn = fmaf(g[d], g[d], nn); }
-            const float inv = 1.f / sqrtf(nn);
-            for (int d = 0; d < a.dd; ++d) x[d] = g[d] * inv;
+            float nsq = 0.f;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) if (d < a.dd) nsq = fmaf(nrm[d], nrm[d], nsq);
+            const float inv = 1.f / sqrtf(nsq);
+#pragma unroll
+            for (int d = 0; d < 16; ++d) if (d < a.dd) x[d] = nrm[d] * inv;
             for (int d = a.dd; d < a.D; ++d) x[d] = 0.f;
         }
+        return;
     }
     if (!a.z1) return;
-    // latent draw of model.py:227 in its column order: z[:, :L] = z1, z[:, L:] = z2  (vae.py:127-128)
-    s.tag = a.tag + 0x40000000u; s.q = 0; s.have = 0;
+    // latent draw of model.py:227 in its column order: z[:, :L] = z1, z[:, L:] = z2  (vae.py:127-128);
+    // normal n of a row is element n & 3 of Philox block n >> 2 under tag + 2^30
+    const int nzb = (a.L + a.D + 3) / 4;
+    const long long zi = item - nx;
+    if (zi >= (long long)a.rows * nzb) return;
+    const int i = (int)(zi / nzb), q = (int)(zi % nzb);
+    float n[4];
+    normals4(philox4x32_10(make_uint4((unsigned)(a.row0 + i), (unsigned)q, step, a.tag + 0x40000000u), key), n);
+    const int c0 = 4 * q;
     float* z1 = a.z1 + (long long)i * a.L;
     float* z2 = a.z2 + (long long)i * a.D;
-    for (int l = 0; l < a.L; ++l) z1[l] = s.next();
-    for (int d = 0; d < a.D; ++d) z2[d] = s.next();
+    if (c0 + 3 < a.L && a.L % 4 == 0) {
+        *reinterpret_cast<float4*>(z1 + c0) = make_float4(n[0], n[1], n[2], n[3]);
+    } else if (c0 >= a.L && (c0 - a.L) + 3 < a.D && a.D % 4 == 0 && a.L % 4 == 0) {
+        *reinterpret_cast<float4*>(z2 + (c0 - a.L)) = make_float4(n[0], n[1], n[2], n[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + k;
+            if (c < a.L) z1[c] = n[k];
+            else if (c < a.L + a.D) z2[c - a.L] = n[k];
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void rng_fill_kernel(float* out_n, unsigned* out_u, long long n, unsigned long long seed,
@@ -124,7 +166,8 @@ int vaek_make_batch(vaek_ctx* ctx, int32_t kind, const float* A, int32_t dd, int
     g_prof = &ctx->prof;
     {
         ProfScope ps("make_batch", (hipStream_t)stream);
-        launch_k(ps, make_batch_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+        const long long items = (x ? rows : 0) + (z1 ? (long long)rows * ((a.L + a.D + 3) / 4) : 0);
+        launch_k(ps, make_batch_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     }
     g_prof = nullptr;
     VAEK_HIP_CHECK(hipGetLastError());
