@@ -112,29 +112,53 @@ def make_batches(w, B, device, nbuf, seed):
 
 
 def cpu_baseline(w, B, seconds):
-    """The torch float32 restatement (oracle/elbo_torch.py) of the same train step on the host
-    cores: "CPU restatement (torch), not JAX" (BASELINE.md section 3).  Checker code, timed only here."""
+    """The same train step on the host cores: the C + OpenMP port (oracle/elbo_ref.c, rebuilt here with
+    -march=native, all cores), plus the torch float32 restatement (oracle/elbo_torch.py) for reference --
+    "CPU restatement, not JAX" (the JAX reference cannot run here).  Checker code,
+    timed only in this leg."""
     from oracle import elbo_oracle as O
+    from oracle import elbo_ref as R
     from oracle import elbo_torch as T
-    cfg = O.Config(data_dim(w), w["L"], w["enc"], w["dec"], w["eps"], w["tdv"], w["dataset"])
-    threads = torch.get_num_threads()
-    p = O.init_params(cfg, seed=0)
-    model = T.TorchVAE(cfg, p, dtype=torch.float32)
-    opt = T.make_adam(model, w["lr"])
-    g = torch.Generator().manual_seed(1)
-    x = torch.randn(B, cfg.D, generator=g); z1 = torch.randn(B, cfg.L, generator=g); z2 = torch.randn(B, cfg.D, generator=g)
-    for _ in range(2):
-        T.train_step(model, opt, x, z1, z2)
+    D, L = data_dim(w), w["L"]
+    cfg = O.Config(D, L, w["enc"], w["dec"], w["eps"], w["tdv"], w["dataset"])
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((B, D)).astype(np.float32); z1 = rng.standard_normal((B, L)).astype(np.float32)
+    z2 = rng.standard_normal((B, D)).astype(np.float32)
+    p0 = O.init_params(cfg, seed=0)
+    # C + OpenMP port
+    lib = R.load(native=True)
+    c = R.make_cfg(D, L, w["enc"], w["dec"], w["eps"], w["tdv"], w["dataset"] == "sigmoid")
+    P = cfg.n_params()
+    params = np.ascontiguousarray(O.flatten(cfg, p0), dtype=np.float32); m = np.zeros(P, np.float32); v = np.zeros(P, np.float32)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for t in (1, 2):
+        R.step(lib, c, params, m, v, t, x, z1, z2, w["lr"], nthreads=cores)
     n, t0 = 0, time.perf_counter()
     while True:
-        T.train_step(model, opt, x, z1, z2)
+        R.step(lib, c, params, m, v, 3 + n, x, z1, z2, w["lr"], nthreads=cores)
         n += 1
         dt = time.perf_counter() - t0
-        if dt >= seconds or n >= 2000:
+        if dt >= seconds * 0.7 or n >= 20000:
             break
-    return {"value": B * n / dt, "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"{n} train steps at batch {B} of the same workload, torch-CPU float32 restatement "
-                      f"(oracle/elbo_torch.py), {dt:.1f} s wall"}
+    out = {"value": B * n / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+           "sample": f"{n} train steps at batch {B} of the same workload, C + OpenMP float32 port (oracle/elbo_ref.c, "
+                     f"-O3 -march=native, {cores} threads), {dt:.1f} s wall"}
+    # torch restatement, a few steps only
+    model = T.TorchVAE(cfg, p0, dtype=torch.float32)
+    opt = T.make_adam(model, w["lr"])
+    xt, z1t, z2t = torch.from_numpy(x), torch.from_numpy(z1), torch.from_numpy(z2)
+    T.train_step(model, opt, xt, z1t, z2t)
+    k, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds * 0.3 and k < 200:
+        T.train_step(model, opt, xt, z1t, z2t)
+        k += 1
+    out["torch_restatement_samples_per_s"] = B * max(k, 1) / (time.perf_counter() - t0)
+    out["torch_threads"] = torch.get_num_threads()
+    return out
 
 
 def main():
