@@ -111,6 +111,30 @@ def make_batches(w, B, device, nbuf, seed):
     return out
 
 
+def usable_cores():
+    """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box
+    hands one job a share of a many-core host; oversubscribing it makes an OpenMP loop crawl)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(w, B, seconds):
     """The same train step on the host cores: the C + OpenMP port (oracle/elbo_ref.c, rebuilt here with
     -march=native, all cores), plus the torch float32 restatement (oracle/elbo_torch.py) for reference --
@@ -130,11 +154,8 @@ def cpu_baseline(w, B, seconds):
     c = R.make_cfg(D, L, w["enc"], w["dec"], w["eps"], w["tdv"], w["dataset"] == "sigmoid")
     P = cfg.n_params()
     params = np.ascontiguousarray(O.flatten(cfg, p0), dtype=np.float32); m = np.zeros(P, np.float32); v = np.zeros(P, np.float32)
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = usable_cores()
+    torch.set_num_threads(cores)
     for t in (1, 2):
         R.step(lib, c, params, m, v, t, x, z1, z2, w["lr"], nthreads=cores)
     n, t0 = 0, time.perf_counter()
