@@ -101,10 +101,20 @@ template <bool A_KCONT, bool B_KCONT, int EPI>
 __global__ __launch_bounds__(HNT) void gemm_bf16_kernel(const HGemmArgs g) {
     __shared__ __attribute__((aligned(16))) __bf16 As[HBM_ * HSTR];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[HBN_ * HSTR];
-    const int m0 = blockIdx.y * HBM_, n0 = blockIdx.x * HBN_;
+    // XCD-aware tile order (see gemm_f32.hip): each XCD walks a contiguous run of the x-fastest tile space
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y, nb = gx * gy * gridDim.z;
+        if (nb % 8 == 0) {
+            const unsigned id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+            const unsigned sw = (id % 8) * (nb / 8) + id / 8;
+            bx = sw % gx; by = (sw / gx) % gy; bz = sw / (gx * gy);
+        }
+    }
+    const int m0 = by * HBM_, n0 = bx * HBN_;
     int kbeg = 0, kend = g.K;
     if (EPI == HEPI_DW) {
-        kbeg = blockIdx.z * g.k_per_split;
+        kbeg = bz * g.k_per_split;
         kend = min(g.K, kbeg + g.k_per_split);
     }
     const bool a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) && (A_KCONT ? (kbeg % 4 == 0) : true);
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(HNT) void gemm_bf16_kernel(const HGemmArgs g) {
         }
     }
     float* C = g.C;
-    if (EPI == HEPI_DW) C += (long long)blockIdx.z * g.slab_stride;
+    if (EPI == HEPI_DW) C += (long long)bz * g.slab_stride;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + (lane & 31);

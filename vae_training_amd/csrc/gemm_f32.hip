@@ -89,10 +89,23 @@ template <bool A_KCONT, bool B_KCONT, int EPI>
 __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[BK * LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) float Bs[BK * LDS_STRIDE];
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s), so give each XCD
+    // a CONTIGUOUS run of the linearised (x fastest) tile space: the tiles that share an A row panel / B
+    // column panel then hit the same L2 instead of each fetching the panel again (speed only, never
+    // correctness; needs the tile count divisible by 8, else the natural order is kept).
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y, nb = gx * gy * gridDim.z;
+        if (nb % 8 == 0) {
+            const unsigned id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+            const unsigned sw = (id % 8) * (nb / 8) + id / 8;
+            bx = sw % gx; by = (sw / gx) % gy; bz = sw / (gx * gy);
+        }
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     int kbeg = 0, kend = g.K;
     if (EPI == EPI_DW) {
-        kbeg = blockIdx.z * g.k_per_split;
+        kbeg = bz * g.k_per_split;
         kend = min(g.K, kbeg + g.k_per_split);
     }
     const bool a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) &&
@@ -133,7 +146,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
     if (EPI == EPI_FWD || EPI == EPI_REPARAM) bias = g.bias ? g.bias[col] : 0.f;
     if (EPI == EPI_REPARAM) sdev = expf(0.5f * g.lv[col]);
     float* C = g.C;
-    if (EPI == EPI_DW) C += (long long)blockIdx.z * g.slab_stride;
+    if (EPI == EPI_DW) C += (long long)bz * g.slab_stride;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
