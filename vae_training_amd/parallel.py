@@ -41,38 +41,52 @@ class GradExchange:
         self.p2p_error = None
         want_p2p = mode == "p2p" or (mode == "auto" and engine is not None and engine.grad_len <= P2P_MAX_FLOATS)
         if want_p2p and engine is not None and self.world > 1:
-            ok = False
-            try:
-                self._init_p2p()
-                ok = self._selftest()
-            except Exception as e:                      # p2p is an optimisation; RCCL is always correct
-                self.p2p_error = str(e)
-            # every rank must take the same decision
-            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self._coll_device())
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                self.in_library = True
-            else:
+            self.in_library = self._setup_p2p()
+            if not self.in_library:
                 _lib.check(engine.lib.vaek_comm_destroy(engine.h))
                 if mode == "p2p":
-                    raise RuntimeError(f"p2p gradient exchange unavailable: {self.p2p_error or 'self-test failed on some rank'}")
+                    raise RuntimeError(f"p2p gradient exchange unavailable: {self.p2p_error or 'failed on another rank'}")
         self.mode = "p2p" if self.in_library else "rccl"
 
     def _coll_device(self):
         return torch.device("cpu") if self.dist.get_backend() == "gloo" else self.engine.device
 
-    def _init_p2p(self):
+    def _all_ok(self, ok):
+        """Every rank takes the same decision; every rank executes the same collectives whatever failed locally."""
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self._coll_device())
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    def _guard(self, fn):
+        try:
+            fn()
+            return True
+        except Exception as e:                          # p2p is an optimisation; RCCL is always correct
+            self.p2p_error = str(e)
+            return False
+
+    def _setup_p2p(self):
         eng, dist = self.engine, self.dist
         lib = eng.lib
         handle = (C.c_uint8 * 64)()
-        _lib.check(lib.vaek_comm_create(eng.h, handle))
+        ok = self._guard(lambda: _lib.check(lib.vaek_comm_create(eng.h, handle)))
         mine = torch.tensor(list(handle), dtype=torch.uint8, device=self._coll_device())
         allh = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(allh, mine)
+        if not self._all_ok(ok):
+            return False
         flat = torch.cat(allh).cpu().numpy().tobytes()
         buf = (C.c_uint8 * len(flat)).from_buffer_copy(flat)
-        _lib.check(lib.vaek_comm_init(eng.h, buf))
+        ok = self._guard(lambda: _lib.check(lib.vaek_comm_init(eng.h, buf)))
+        if not self._all_ok(ok):
+            return False
         dist.barrier()
+        ok = False
+        try:
+            ok = self._selftest()
+        except Exception as e:
+            self.p2p_error = str(e)
+        return self._all_ok(ok)
 
     def _selftest(self):
         """Three stand-alone all-reduces (both granule banks) of rank-dependent values against the sum
