@@ -249,9 +249,12 @@ def main():
         x, z1, z2 = batches[i % len(batches)]
         if exch is None or exch.in_library:
             eng.train_step(params, grads, m, v, step_dev, x, z1, z2, lr)
-        else:
+        elif eng.fused:
             eng.grads_only(params, grads, step_dev, x, z1, z2)
             exch.all_reduce(grads)
+            eng.apply(params, grads, m, v, step_dev, lr)
+        else:       # layer-by-layer model: per-layer buckets all-reduced on a side stream under the rest of the backward
+            exch.overlapped_grads(params, grads, step_dev, x, z1, z2)
             eng.apply(params, grads, m, v, step_dev, lr)
 
     def fence():

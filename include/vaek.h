@@ -143,6 +143,18 @@ int vaek_train_step_grads_only(vaek_ctx* ctx, const float* params, float* grads,
                                void* workspace, void* stream);
 int vaek_train_step_apply(vaek_ctx* ctx, float* params, const float* grads, float* m, float* v,
                           const int32_t* step_dev, float lr, void* stream);
+/* Bucketed variant for overlapping the data-parallel exchange with the rest of the backward pass
+ * (layer-by-layer path): the flat gradient is final bucket by bucket, in backward order (decoder's last
+ * layer first, encoder's first layer last, then the tail = epsilon_p, epsilon, loss slots).  Bucket i
+ * covers grads[offset, offset + count) (vaek_bucket_info); ready_events[i] is a caller-owned hipEvent_t
+ * (passed as void*) that the library records on `stream` the moment bucket i is complete, so a
+ * communication stream can wait on it and all-reduce that slice while earlier layers are still in
+ * their dW / dX GEMMs.  The fused small-model path has a single bucket. */
+int vaek_bucket_count(const vaek_ctx* ctx, int32_t* n);
+int vaek_bucket_info(const vaek_ctx* ctx, int32_t i, int64_t* offset, int64_t* count);
+int vaek_train_step_grads_bucketed(vaek_ctx* ctx, const float* params, float* grads, int32_t* step_dev,
+                                   const float* x, const float* z1, const float* z2, void* const* ready_events,
+                                   void* workspace, void* stream);
 /* VAE.loss, networks.py:103-113: out4 = {loss, mean Dkl, mean mse, eps}. */
 int vaek_loss_eval(vaek_ctx* ctx, const float* params, const float* x, const float* z1, const float* z2,
                    float* out4, void* workspace, void* stream);

@@ -50,6 +50,9 @@ SIGNATURES = {
     "vaek_train_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp]),
     "vaek_train_step_grads_only": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vaek_train_step_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp]),
+    "vaek_bucket_count": (C.c_int, [_vp, C.POINTER(_i32)]),
+    "vaek_bucket_info": (C.c_int, [_vp, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
+    "vaek_train_step_grads_bucketed": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vaek_loss_eval": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vaek_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _i32, _vp, _vp]),
     "vaek_comm_buffer_bytes": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <new>
+#include <utility>
 
 #include "vaek_internal.h"
 
@@ -94,8 +95,12 @@ static int net_forward(vaek_ctx* c, const Net& net, const float* params, const f
 
 // ---- backward through one stack.  d_out: gradient w.r.t. the last Dense output (lives in the
 // stack's last activation buffer).  dx_first: where dL/d(input) goes (nullptr: not needed).
+struct BucketSink {          // bucketed mode: where finished layers go and which event announces them
+    float* grads; void* const* events; int next;
+};
+
 static int net_backward(vaek_ctx* c, const Net& net, const float* params, const float* in, float* d_out, void* ws,
-                        float* dx_first, bool accumulate_first, hipStream_t st) {
+                        float* dx_first, bool accumulate_first, hipStream_t st, BucketSink* sink = nullptr) {
     float* d = d_out;
     float* gb[2] = {at<float>(ws, c->ws_gbuf0), at<float>(ws, c->ws_gbuf1)};
     int tog = 0;
@@ -108,6 +113,11 @@ static int net_backward(vaek_ctx* c, const Net& net, const float* params, const 
         int rc = (h16 ? launch_dense_bwd_dw_bf16 : launch_dense_bwd_dw)(h_in, d, slabs + l.w_off, c->P, l.S, l.rows_per_split,
                                                                         c->B, l.n_in, l.n_out, st);
         if (rc) return rc;
+        if (sink) {     // this layer's [kernel | bias] slice is final once its slabs are summed: announce it
+            const int64_t cnt = (int64_t)(l.n_in + 1) * l.n_out;
+            if ((rc = launch_sum_slabs(slabs + l.w_off, c->P, l.S, sink->grads + l.w_off, cnt, st))) return rc;
+            VAEK_HIP_CHECK(hipEventRecord((hipEvent_t)sink->events[sink->next++], st));
+        }
         if (i > 0) {
             float* dx = gb[tog];
             tog ^= 1;
@@ -124,7 +134,7 @@ static int net_backward(vaek_ctx* c, const Net& net, const float* params, const 
 }
 
 static int generic_grads(vaek_ctx* c, const float* params, int32_t* step_dev, const float* x, const float* z1,
-                         const float* z2, void* ws, hipStream_t st) {
+                         const float* z2, void* ws, hipStream_t st, BucketSink* sink = nullptr) {
     const bool sig = c->cfg.sigmoid_decoder != 0;
     const float inv_bt = (float)(1.0 / (double)c->Bt);
     int rc;
@@ -145,17 +155,18 @@ static int generic_grads(vaek_ctx* c, const float* params, int32_t* step_dev, co
     e.inv_bt = inv_bt; e.step_dev = step_dev;
     if ((rc = launch_elbo(e, st))) return rc;
     float* dsamp = at<float>(ws, c->ws_dsamp);
-    if ((rc = net_backward(c, c->dec, params, samples, y_lin, ws, dsamp, false, st))) return rc;
-    if (sig && (rc = net_backward(c, c->sig, params, samples, y_sig, ws, dsamp, true, st))) return rc;
+    if ((rc = net_backward(c, c->dec, params, samples, y_lin, ws, dsamp, false, st, sink))) return rc;
+    if (sig && (rc = net_backward(c, c->sig, params, samples, y_sig, ws, dsamp, true, st, sink))) return rc;
     if ((rc = launch_reparam_bwd(dsamp, mu, z1, at<float>(ws, c->ws_rpart), c->B, c->L, c->Se, c->rows_per_esplit,
                                  inv_bt, st)))
         return rc;
-    return net_backward(c, c->enc, params, x, dsamp, ws, nullptr, false, st);
+    return net_backward(c, c->enc, params, x, dsamp, ws, nullptr, false, st, sink);
 }
 
 static int generic_finalize(vaek_ctx* c, const float* params, float* grads, float* params_rw, float* m, float* v,
-                            const int32_t* step_dev, float lr, void* ws, hipStream_t st) {
+                            const int32_t* step_dev, float lr, void* ws, hipStream_t st, int64_t lo = 0) {
     FinalizeArgs f{};
+    f.lo = lo;
     f.slabs = at<float>(ws, c->ws_slabs); f.slab_stride = c->P; f.S = c->S;
     f.nseg = 0;
     for (const Net* net : {&c->enc, &c->dec, &c->sig})
@@ -444,6 +455,57 @@ int vaek_train_step(vaek_ctx* ctx, float* params, float* grads, float* m, float*
     if (ctx->fused) return fused_train_step(ctx, params, grads, m, v, step_dev, x, z1, z2, lr, true, false, workspace, st);
     if ((rc = generic_grads(ctx, params, step_dev, x, z1, z2, workspace, st))) return rc;
     return generic_finalize(ctx, params, grads, params, m, v, step_dev, lr, workspace, st);
+}
+
+// buckets in the order the backward pass completes them: Decoder (last layer first), SigDecoder, Encoder, tail
+static void bucket_list(const vaek_ctx* c, std::vector<std::pair<int64_t, int64_t>>& out) {
+    out.clear();
+    if (c->fused) { out.push_back({0, c->P + kExtra}); return; }
+    for (const Net* net : {&c->dec, &c->sig, &c->enc})
+        for (int i = (int)net->layers.size() - 1; i >= 0; --i) {
+            const auto& l = net->layers[i];
+            out.push_back({l.w_off, (int64_t)(l.n_in + 1) * l.n_out});
+        }
+    out.push_back({c->off_epsp, c->P + kExtra - c->off_epsp});
+}
+
+int vaek_bucket_count(const vaek_ctx* ctx, int32_t* n) {
+    if (!ctx || !n) { set_error("null argument"); return VAEK_ERR_INVALID; }
+    std::vector<std::pair<int64_t, int64_t>> b;
+    bucket_list(ctx, b);
+    *n = (int32_t)b.size();
+    return VAEK_OK;
+}
+
+int vaek_bucket_info(const vaek_ctx* ctx, int32_t i, int64_t* offset, int64_t* count) {
+    if (!ctx || !offset || !count) { set_error("null argument"); return VAEK_ERR_INVALID; }
+    std::vector<std::pair<int64_t, int64_t>> b;
+    bucket_list(ctx, b);
+    if (i < 0 || i >= (int32_t)b.size()) { set_error("bucket index out of range"); return VAEK_ERR_INVALID; }
+    *offset = b[i].first; *count = b[i].second;
+    return VAEK_OK;
+}
+
+int vaek_train_step_grads_bucketed(vaek_ctx* ctx, const float* params, float* grads, int32_t* step_dev, const float* x,
+                                   const float* z1, const float* z2, void* const* ready_events, void* workspace, void* stream) {
+    ProfBind pb(ctx);
+    if (!ctx || !params || !grads || !step_dev || !x || !z1 || !z2 || !ready_events) { set_error("vaek_train_step_grads_bucketed: null argument"); return VAEK_ERR_INVALID; }
+    int rc = check_ws(ctx, workspace);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (ctx->fused) {
+        if ((rc = fused_train_step(ctx, const_cast<float*>(params), grads, nullptr, nullptr, step_dev, x, z1, z2, 0.f, false, false,
+                                   workspace, st)))
+            return rc;
+        VAEK_HIP_CHECK(hipEventRecord((hipEvent_t)ready_events[0], st));
+        return VAEK_OK;
+    }
+    BucketSink sink{grads, ready_events, 0};
+    if ((rc = generic_grads(ctx, params, step_dev, x, z1, z2, workspace, st, &sink))) return rc;
+    // tail: epsilon_p, epsilon and the loss slots (everything the layer buckets did not cover)
+    if ((rc = generic_finalize(ctx, params, grads, nullptr, nullptr, nullptr, nullptr, 0.f, workspace, st, ctx->off_epsp))) return rc;
+    VAEK_HIP_CHECK(hipEventRecord((hipEvent_t)ready_events[sink.next], st));
+    return VAEK_OK;
 }
 
 int vaek_loss_eval(vaek_ctx* ctx, const float* params, const float* x, const float* z1, const float* z2, float* out4,

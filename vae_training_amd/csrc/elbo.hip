@@ -185,7 +185,7 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeArgs a) {
     } else {
         __syncthreads();
     }
-    const bool live = q == 0 && i >= 0;
+    const bool live = q == 0 && i >= 0 && i >= a.lo;
     float g = live ? sums[o] : 0.f;
     const long long base = n - 64ll * ((long long)blockIdx.x + 1);
     if (!live) {

@@ -155,6 +155,7 @@ struct FinalizeArgs {
     // optional fused Adam (world == 1): params_rw != nullptr
     float* params_rw; float* m; float* v; const int32_t* step_dev; float lr;
     float* loss_hist; long long loss_hist_cap;    // optional: loss of Adam step t -> loss_hist[(t-1) % cap]
+    long long lo;             // outputs below lo are left alone (bucketed mode finalises the tail only)
 };
 int launch_finalize(const FinalizeArgs& a, hipStream_t st);
 int launch_adam(float* params, const float* grads, float* m, float* v, int64_t n, float lr, int step,

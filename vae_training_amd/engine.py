@@ -114,6 +114,24 @@ class Engine:
         _lib.check(self.lib.vaek_train_step_grads_only(self.h, _ptr(params), _ptr(grads), _ptr(step_dev), _ptr(x),
                                                        _ptr(z1), _ptr(z2), _ptr(self.workspace), _stream()))
 
+    def buckets(self):
+        """[(offset, count)] of the gradient buckets in the order the backward pass completes them."""
+        n = C.c_int32()
+        _lib.check(self.lib.vaek_bucket_count(self.h, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            off, cnt = C.c_int64(), C.c_int64()
+            _lib.check(self.lib.vaek_bucket_info(self.h, i, C.byref(off), C.byref(cnt)))
+            out.append((off.value, cnt.value))
+        return out
+
+    def grads_bucketed(self, params, grads, step_dev, x, z1, z2, events):
+        """Like grads_only, but records events[i] (torch.cuda.Event, already created on this device) the moment
+        bucket i of `grads` is final."""
+        arr = (C.c_void_p * len(events))(*[C.c_void_p(e.cuda_event) for e in events])
+        _lib.check(self.lib.vaek_train_step_grads_bucketed(self.h, _ptr(params), _ptr(grads), _ptr(step_dev), _ptr(x), _ptr(z1),
+                                                           _ptr(z2), arr, _ptr(self.workspace), _stream()))
+
     def apply(self, params, grads, m, v, step_dev, lr):
         _lib.check(self.lib.vaek_train_step_apply(self.h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v),
                                                   _ptr(step_dev), float(lr), _stream()))

@@ -113,6 +113,28 @@ class GradExchange:
         _lib.check(self.engine.lib.vaek_comm_status(self.engine.h, C.byref(t)))
         return bool(t.value)
 
+    # ---- RCCL path with communication overlapped with the backward pass (layer-by-layer models) --------
+    def overlapped_grads(self, params, grads, step_dev, x, z1, z2):
+        """vaek_train_step_grads_bucketed + one all-reduce per gradient bucket on a side stream: the all-reduce
+        of the decoder's last layer runs while the encoder is still in its dW / dX GEMMs (the order RCCL sees
+        is the order the backward pass finishes the buckets in, identical on every rank).  On return the
+        current stream has waited for every exchange: `grads` is the global sum."""
+        eng = self.engine
+        if not hasattr(self, "_buckets"):
+            self._buckets = eng.buckets()
+            self._events = [torch.cuda.Event() for _ in self._buckets]
+            for e in self._events:
+                e.record()                                  # materialise the hipEvent_t handles
+            self._comm_stream = torch.cuda.Stream(device=eng.device)
+        main = torch.cuda.current_stream()
+        eng.grads_bucketed(params, grads, step_dev, x, z1, z2, self._events)
+        for (off, cnt), ev in zip(self._buckets, self._events):
+            self._comm_stream.wait_event(ev)
+            with torch.cuda.stream(self._comm_stream):
+                self.all_reduce(grads[off:off + cnt])
+        main.wait_stream(self._comm_stream)
+        return grads
+
     def all_reduce(self, grads: torch.Tensor):
         """SUM over ranks, in place (RCCL; gloo for CPU tensors and one-GPU rehearsals)."""
         if self.world == 1:
