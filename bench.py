@@ -342,6 +342,8 @@ def main():
                         "algorithmic_per_launch": alg,
                         "step_kernels_us": {k: r["total_ms"] / args.steps * 1e3 for k, r in rep.items()},
                         "param_bytes_per_step": 32 * P}
+            if rank == 0:       # the same denominators re-measured on THIS box by the library's micro-benchmarks
+                roofline["peak_measured"] = eng.measure_peaks()
 
     # ---- auxiliary (never `value`): the same step with FRESH inputs drawn on the device every step, as the
     # reference's loop does (dataset.get_batch + sample_latent, model.py:221 / vae.py:125-128): one Philox

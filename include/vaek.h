@@ -200,6 +200,14 @@ int vaek_rng_fill(vaek_ctx* ctx, float* normals, uint32_t* bits, int64_t n, uint
  * t = Adam step (what the reference appends to vae_losses, vae.py:130, without a per-step copy). */
 int vaek_set_loss_history(vaek_ctx* ctx, float* buf, int64_t cap);
 
+/* ---- roofline denominators measured on the box (bench.py; not on the train-step path) -------------- */
+/* float4 stream copy of `bytes` (multiple of 16) src -> dst; time it with vaek_profile_*. */
+int vaek_microbench_copy(vaek_ctx* ctx, const void* src, void* dst, int64_t bytes, void* stream);
+/* Back-to-back MFMA loop, independent accumulators: kind 0 = v_mfma_f32_16x16x4_f32, 1 =
+ * v_mfma_f32_32x32x16_bf16; `waves_per_simd` workgroups of 4 waves per CU.  *flops_out = flops of the launch. */
+int vaek_microbench_mfma(vaek_ctx* ctx, int32_t kind, int32_t iters, int32_t waves_per_simd, float* scratch,
+                         double* flops_out, void* stream);
+
 /* ---- in-process kernel timing (bench.py's roofline leg) --------------------------------------- */
 /* Between begin and report every kernel the library launches for this context is bracketed by a
  * pair of hipEvents recorded on the launch stream (pool of max_records pairs, allocated here, so

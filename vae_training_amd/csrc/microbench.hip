@@ -1,0 +1,90 @@
+// Roofline denominators measured on the box ("the harness must re-measure with its own
+// stream-copy and MFMA micro-benchmarks ... and report both"): a float4 stream copy for achievable HBM
+// bandwidth and back-to-back MFMA loops (independent accumulators, one wave per SIMD and more) for the
+// f32 / bf16 matrix-core rates.  bench.py calls these through vaek_microbench_*; they are not on the
+// train-step path.
+#include "vaek_internal.h"
+
+namespace vaek {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+__global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+template <int KIND>   // 0: v_mfma_f32_16x16x4_f32, 1: v_mfma_f32_32x32x16_bf16
+__global__ __launch_bounds__(256) void mfma_loop_kernel(float* out, int iters) {
+    const float a0 = 1.0f + 1e-3f * (threadIdx.x & 7), b0 = 0.5f + 1e-3f * (threadIdx.x & 3);
+    float sink = 0.f;
+    if (KIND == 0) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[k], 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sink += acc[k][0];
+    } else {
+        f32x16 acc[2];
+        bf16x8 a, b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(a0 + 0.01f * j); b[j] = (__bf16)(b0 - 0.01f * j); }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[k], 0, 0, 0);
+        }
+        sink = acc[0][0] + acc[1][0];
+    }
+    if (sink == 12345.678f) out[0] = sink;      // keep the chain live without a store on the timed path
+}
+
+}  // namespace vaek
+
+using namespace vaek;
+
+extern "C" {
+
+int vaek_microbench_copy(vaek_ctx* ctx, const void* src, void* dst, int64_t bytes, void* stream) {
+    if (!ctx || !src || !dst || bytes <= 0 || bytes % 16) { set_error("vaek_microbench_copy: invalid argument"); return VAEK_ERR_INVALID; }
+    g_prof = &ctx->prof;
+    {
+        ProfScope ps("microbench_stream_copy", (hipStream_t)stream);
+        launch_k(ps, stream_copy_kernel, dim3(ctx->n_cu * 8), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst,
+                 (long long)(bytes / 16));
+    }
+    g_prof = nullptr;
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+/* kind 0: f32 16x16x4 (4 MFMAs/iter, 2048 flop each per wave); kind 1: bf16 32x32x16 (2 MFMAs/iter, 32768 flop each).
+ * flops_out = total flops of the launch (host-computed). */
+int vaek_microbench_mfma(vaek_ctx* ctx, int32_t kind, int32_t iters, int32_t waves_per_simd, float* scratch, double* flops_out,
+                         void* stream) {
+    if (!ctx || (kind != 0 && kind != 1) || iters <= 0 || waves_per_simd <= 0 || waves_per_simd > 8 || !scratch || !flops_out) {
+        set_error("vaek_microbench_mfma: invalid argument");
+        return VAEK_ERR_INVALID;
+    }
+    const int blocks = ctx->n_cu * waves_per_simd;               // 256 threads = 4 waves = one per SIMD per block
+    *flops_out = (double)blocks * 4.0 * iters * (kind == 0 ? 4.0 * 2.0 * 16 * 16 * 4 : 2.0 * 2.0 * 32 * 32 * 16);
+    g_prof = &ctx->prof;
+    {
+        ProfScope ps(kind == 0 ? "microbench_mfma_f32" : "microbench_mfma_bf16", (hipStream_t)stream);
+        if (kind == 0) launch_k(ps, mfma_loop_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, scratch, (int)iters);
+        else launch_k(ps, mfma_loop_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, scratch, (int)iters);
+    }
+    g_prof = nullptr;
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+}  // extern "C"

@@ -187,6 +187,34 @@ class Engine:
         _lib.check(self.lib.vaek_profile_report(self.h, buf, 8192))
         return json.loads(buf.value.decode())
 
+    def measure_peaks(self, copy_bytes=1 << 30, reps=5):
+        """Achievable HBM bandwidth (float4 stream copy, read + write bytes) and f32 / bf16 MFMA rates measured on
+        this device with the library's own micro-benchmarks."""
+        src = torch.empty(copy_bytes, dtype=torch.uint8, device=self.device).random_(0, 255)
+        dst = torch.empty_like(src)
+        scratch = torch.zeros(16, dtype=torch.float32, device=self.device)
+        flops = C.c_double()
+        st = _stream()
+        plan = [("microbench_mfma_f32", 0, 4000, 2), ("microbench_mfma_bf16", 1, 4000, 2)]
+        for _ in range(2):                                   # warm-up
+            _lib.check(self.lib.vaek_microbench_copy(self.h, _ptr(src), _ptr(dst), copy_bytes, st))
+            for _, kind, iters, wps in plan:
+                _lib.check(self.lib.vaek_microbench_mfma(self.h, kind, iters, wps, _ptr(scratch), C.byref(flops), st))
+        torch.cuda.synchronize()
+        self.profile_begin(64)
+        fl = {}
+        for _ in range(reps):
+            _lib.check(self.lib.vaek_microbench_copy(self.h, _ptr(src), _ptr(dst), copy_bytes, st))
+            for name, kind, iters, wps in plan:
+                _lib.check(self.lib.vaek_microbench_mfma(self.h, kind, iters, wps, _ptr(scratch), C.byref(flops), st))
+                fl[name] = flops.value
+        torch.cuda.synchronize()
+        rep = self.profile_report()
+        out = {"hbm_copy_GBps": 2.0 * copy_bytes * rep["microbench_stream_copy"]["count"] / (rep["microbench_stream_copy"]["total_ms"] * 1e-3) / 1e9}
+        for name, _, _, _ in plan:
+            out[name.replace("microbench_", "") + "_TFLOPs"] = fl[name] * rep[name]["count"] / (rep[name]["total_ms"] * 1e-3) / 1e12
+        return out
+
     # ---- building blocks -----------------------------------------------------------------------
     def dense_fwd(self, x, w, b, relu=False):
         rows, n_in = x.shape
