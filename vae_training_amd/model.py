@@ -70,6 +70,8 @@ class GenerativeModel(Model):
             pass
 
     def plot_epoch(self):
+        if getattr(self, "rank", 0) != 0:
+            return
         key, self.key = vrandom.split(self.key)
         batch = self.sample_batch(key, self.plot_batch_size)[0]
         fn = os.path.join(self.dirname, f"output_{self.batchnum}.png")
@@ -112,6 +114,8 @@ class GenerativeModel(Model):
         self._write(message)
 
     def _write(self, message):
+        if getattr(self, "rank", 0) != 0:
+            return
         if self.tqdm:
             try:
                 from tqdm import tqdm
@@ -129,7 +133,8 @@ class GenerativeModel(Model):
         one dataset batch + one train step per iteration."""
         eval_batch = self.dataset.get_batch(self.print_batch_size)
         score = self.dataset.score_batch(eval_batch)
-        print(f"Score for real data: { {k: float(v) for k, v in score.items()} if isinstance(score, dict) else score}")
+        if getattr(self, "rank", 0) == 0:
+            print(f"Score for real data: { {k: float(v) for k, v in score.items()} if isinstance(score, dict) else score}")
         it = range(self.num_batches)
         if self.tqdm:
             try:
@@ -168,6 +173,8 @@ class GenerativeModel(Model):
         loop.run(self.num_batches - pos)
 
     def save(self, final=False):
+        if getattr(self, "rank", 0) != 0:          # replicas are identical: rank 0 writes losses.npz / model.pkl
+            return
         data = self.model_save_data(final=final)
         data["Average Log Likelihood"] = np.array([_to_numpy(a) for a in self.average_log_likelihoods])
         stats = deepcopy(dict(self.stats))

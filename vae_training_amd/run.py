@@ -41,6 +41,9 @@ def build_parser():
     p.add_argument("-off", "--latent_off_dimension", type=int, default=1)
     p.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: current)")
     p.add_argument("--force_generic", action="store_true", help="layer-by-layer kernels even where a fused path exists")
+    p.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="Dense GEMM arithmetic (bf16: wide layers on bf16 MFMA)")
+    p.add_argument("--dist_backend", default="nccl", choices=["nccl", "gloo"],
+                   help="process-group backend when launched with torch.distributed.run (gloo: one-GPU rehearsal)")
     p.add_argument("--fast_loop", action="store_true",
                    help="run the steps between stats/plots from a hipGraph with on-device Philox batches (trainer.py)")
     return p
@@ -54,43 +57,95 @@ def parse_arguments(argv=None):
     return args
 
 
-def get_dataset(name, seed, padding_dimension, batch_size, args):
+def get_dataset(name, seed, padding_dimension, batch_size, args, world=1, rank=0):
+    from . import random as vrandom
     from .datasets import LinearGaussianDataset, SigmoidDataset, SphereDataset
     dev = None if getattr(args, "device", None) is None else f"cuda:{args.device}"
+    ds = None
     if name == "sphere":
-        return SphereDataset(seed, dimension=args.dataset_dimension, padding_dimension=args.padding_dim, device=dev)
-    if name == "linear_gaussian":
-        return LinearGaussianDataset(seed, dimension=args.dataset_dimension,
-                                     intrinsic_dimension=args.dataset_intrinsic_dimension,
-                                     padding_dimension=args.padding_dim, var_added=args.dataset_noise, device=dev)
-    if name == "sigmoid":
-        return SigmoidDataset(seed, dimension=args.dataset_dimension, padding_dimension=args.padding_dim, device=dev)
-    return None
+        ds = SphereDataset(seed, dimension=args.dataset_dimension, padding_dimension=args.padding_dim, device=dev)
+    elif name == "linear_gaussian":
+        ds = LinearGaussianDataset(seed, dimension=args.dataset_dimension,
+                                   intrinsic_dimension=args.dataset_intrinsic_dimension,
+                                   padding_dimension=args.padding_dim, var_added=args.dataset_noise, device=dev)
+    elif name == "sigmoid":
+        ds = SigmoidDataset(seed, dimension=args.dataset_dimension, padding_dimension=args.padding_dim, device=dev)
+    if ds is not None and world > 1:
+        # same manifold (A was drawn from the seed above) on every rank, a different sample stream per rank
+        ds.key = vrandom.split(ds.key, world)[rank]
+    return ds
 
 
-def get_model(args, dataset, output_dir):
+def get_model(args, dataset, output_dir, dist=None):
+    from . import random as vrandom
     from .vae import VAEModel
     if args.model != "VAE":
         raise NameError(f"model {args.model!r}: only the VAE branch exists (run.py:250-268)")
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    if world > 1:
+        return _get_model_dp(args, dataset, output_dir, dist, world, rank)
     return VAEModel(dirname=output_dir, batch_size=args.batch_size, learning_rate=args.learning_rate, dataset=dataset,
                     num_batches=args.num_batches, num_epochs=args.num_epochs, layer_sizes=args.layer_sizes,
                     encoder_layer_sizes=args.encoder_layer_sizes, state_dict=args.state_dict, data_fn=args.data_fn,
                     epsilon=args.epsilon, tqdm=args.tqdm, latent_dimension=args.latent_dimension,
                     tunable_decoder_var=args.tunable_decoder_var, warm_start=args.warm_start,
                     dataset_name=args.dataset, latent_off_dimension=args.latent_off_dimension,
-                    force_generic=getattr(args, "force_generic", False), fast_loop=getattr(args, "fast_loop", False))
+                    force_generic=getattr(args, "force_generic", False), fast_loop=getattr(args, "fast_loop", False),
+                    dtype=getattr(args, "dtype", "f32"))
+
+
+def _get_model_dp(args, dataset, output_dir, dist, world, rank):
+    """Data parallel (this build's addition; the reference is single-device): --batch_size is the GLOBAL
+    batch, every rank trains on batch_size / world rows of its own sample stream, gradients are summed
+    over ranks (parallel.GradExchange: P2P inside the finalize kernel, or RCCL overlapped with the
+    backward pass) and every replica applies the identical Adam update."""
+    from . import random as vrandom
+    from .parallel import GradExchange, shard_rows
+    from .vae import VAEModel
+    lo, hi = shard_rows(args.batch_size, world, rank)
+    m = VAEModel(dirname=output_dir, batch_size=hi - lo, learning_rate=args.learning_rate, dataset=dataset,
+                 num_batches=args.num_batches, num_epochs=args.num_epochs, layer_sizes=args.layer_sizes,
+                 encoder_layer_sizes=args.encoder_layer_sizes, state_dict=args.state_dict, data_fn=args.data_fn,
+                 epsilon=args.epsilon, tqdm=args.tqdm and rank == 0, latent_dimension=args.latent_dimension,
+                 tunable_decoder_var=args.tunable_decoder_var, warm_start=args.warm_start, dataset_name=args.dataset,
+                 latent_off_dimension=args.latent_off_dimension, force_generic=getattr(args, "force_generic", False),
+                 dtype=getattr(args, "dtype", "f32"), world=world, rank=rank, global_batch=args.batch_size)
+    eng = m.model.module.engine(hi - lo, args.batch_size)
+    m.optimizer.exchange = GradExchange(eng, dist)
+    m.key = vrandom.split(m.key, world)[rank]              # identical initial parameters, different latent draws
+    m.rank = rank
+    return m
 
 
 def main(args):
-    from .utils import make_output_dir
-    output_dir = make_output_dir(args.name, args.overwrite, args)
-    dataset = get_dataset(args.dataset, args.dataset_seed, args.padding_dim, args.batch_size, args)
+    import os
+
+    from .utils import get_output_dir, make_output_dir
+    dist = None
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0")) if args.dist_backend == "nccl" else 0
+        torch.cuda.set_device(local)
+        args.device = local
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    if rank == 0:
+        output_dir = make_output_dir(args.name, args.overwrite, args)
+    if dist is not None:
+        dist.barrier()
+        output_dir = get_output_dir(args.name)
+    dataset = get_dataset(args.dataset, args.dataset_seed, args.padding_dim, args.batch_size, args, world, rank)
     if dataset is None:
         raise ValueError("--dataset must be one of sphere, linear_gaussian, sigmoid")
-    model = get_model(args, dataset, output_dir)
+    model = get_model(args, dataset, output_dir, dist)
     model.train()
     model.plot()
     model.save(final=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
     return 0
 
 

@@ -20,7 +20,7 @@ class VAEModel(GenerativeModel):
     def __init__(self, dirname, num_batches, num_epochs, batch_size, learning_rate, layer_sizes,
                  encoder_layer_sizes, state_dict, data_fn, epsilon, tqdm, dataset, latent_dimension,
                  tunable_decoder_var=False, warm_start=False, dataset_name=None, latent_off_dimension=0,
-                 exchange=None, global_batch=0, world=1, rank=0, force_generic=False, fast_loop=False):
+                 exchange=None, global_batch=0, world=1, rank=0, force_generic=False, fast_loop=False, dtype="f32"):
         super().__init__(dirname=dirname, num_batches=num_batches, num_epochs=num_epochs, batch_size=batch_size,
                          learning_rate=learning_rate, latent_distribution="gaussian",
                          latent_dimension=latent_dimension, dataset=dataset, state_dict=state_dict,
@@ -39,7 +39,7 @@ class VAEModel(GenerativeModel):
         device = dataset.device if getattr(dataset, "device", None) is not None else None
         vae_module = VAE.partial(epsilon=epsilon, encoder_layer_sizes=enc, decoder_layer_sizes=dec,
                                  tunable_decoder_var=tunable_decoder_var, dataset_name=dataset_name,
-                                 device=device, world=world, rank=rank, force_generic=force_generic)
+                                 device=device, world=world, rank=rank, force_generic=force_generic, dtype=dtype)
         _, initial_params = vae_module.init_by_shape(vae_key, [(data_size,), (latent_dimension,), (data_size,)])
         self.model = Model(vae_module, initial_params)
         self.optimizer = Adam(learning_rate=self.learning_rate).create(self.model, exchange=exchange,
