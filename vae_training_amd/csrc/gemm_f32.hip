@@ -7,7 +7,7 @@
 //   forward   Y[B,N]   = act(X[B,K] W[K,N] + b)            A: k-contiguous, B: n-contiguous
 //   dX        dX[B,K]  = (dY[B,N] W^T) * relu'(X)          A: k-contiguous, B: k-contiguous
 //   dW | db   G[K+1,N] = [X | 1]^T dY   split over batch   A: m-contiguous (+ones row), B: n-contiguous
-// Block = 256 threads = 4 waves, 64x64 output tile, each wave one 32x32 MFMA tile, BK = 16.
+// Block = 256 threads = 4 waves, each wave one 32x32 MFMA tile; output tile 64x64, 128x32 or 32x128; BK = 16.
 // LDS tiles are k-major ([k][m] / [k][n]) so every MFMA operand read is 32 consecutive floats
 // (conflict-free ds_read_b32); the next K-tile is fetched into registers while the MFMAs of the
 // current one run (issue-early / write-late staging).
@@ -17,7 +17,11 @@ namespace vaek {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int BM = 64, BN = 64, BK = 16, LDS_STRIDE = 68, NT = 256;
+constexpr int BK = 16, NT = 256;
+// Tile shapes: WM x WN waves of 32x32 each (WM * WN = 4): 2x2 = 64x64 for square-ish layers, 4x1 = 128x32
+// for skinny outputs (N <= 32: the latent / data dims of every VAE here), 1x4 = 32x128 for skinny M (the
+// dW|db of an input layer with a handful of features).  With a 64-wide tile a 20-column output keeps half
+// of each block's MFMAs busy on columns nobody stores.
 
 enum { EPI_FWD = 0, EPI_REPARAM = 1, EPI_DX = 2, EPI_DW = 3 };
 
@@ -34,61 +38,84 @@ struct GemmArgs {
     int k_per_split; long long slab_stride;   // DW
 };
 
-// (mn, k) element at p[mn*ld + k]; tile 64 (mn) x 16 (k); thread -> row t>>2, 4 consecutive k.
-__device__ __forceinline__ void fetch_kcont(const float* __restrict__ p, int ld, int mn0, int MN, int k0,
-                                            int kend, bool vec_ok, float (&v)[4]) {
-    const int t = threadIdx.x;
-    const int mn = mn0 + (t >> 2);
-    const int k = k0 + (t & 3) * 4;
-    v[0] = v[1] = v[2] = v[3] = 0.f;
-    if (mn < MN) {
-        const float* q = p + (long long)mn * ld + k;
-        if (vec_ok && k + 3 < kend) {
-            const float4 f = *reinterpret_cast<const float4*>(q);
-            v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
-        } else {
+// Operand tile = T (mn) x 16 (k) floats, staged k-major into LDS rows of T + 4 floats.
+// k-contiguous source p[mn*ld + k]: float4 unit u -> row u >> 2, k = 4 (u & 3); U = T*4 units over 256 threads.
+template <int T>
+__device__ __forceinline__ void fetch_kcont(const float* __restrict__ p, int ld, int mn0, int MN, int k0, int kend,
+                                            bool vec_ok, float (&v)[(T * 4 + NT - 1) / NT][4]) {
+    constexpr int NU = (T * 4 + NT - 1) / NT;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) if (k + c < kend) v[c] = q[c];
-        }
-    }
-}
-__device__ __forceinline__ void store_kcont(float* s, const float (&v)[4]) {
-    const int t = threadIdx.x;
-    const int mn = t >> 2, k = (t & 3) * 4;
+    for (int i = 0; i < NU; ++i) {
+        const int u = threadIdx.x + i * NT;
+        v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+        if (u >= T * 4) continue;
+        const int mn = mn0 + (u >> 2), k = k0 + (u & 3) * 4;
+        if (mn < MN) {
+            const float* q = p + (long long)mn * ld + k;
+            if (vec_ok && k + 3 < kend) {
+                const float4 f = *reinterpret_cast<const float4*>(q);
+                v[i][0] = f.x; v[i][1] = f.y; v[i][2] = f.z; v[i][3] = f.w;
+            } else {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) s[(k + c) * LDS_STRIDE + mn] = v[c];
-}
-// (mn, k) element at p[k*ld + mn]; tile 16 (k) x 64 (mn); thread -> k row t>>4, 4 consecutive mn.
-// mn == mem (>= 0 only for the augmented operand) reads as 1, mn > mem as 0.
-__device__ __forceinline__ void fetch_mncont(const float* __restrict__ p, int ld, int mn0, int mem, bool aug,
-                                             int k0, int kend, bool vec_ok, float (&v)[4]) {
-    const int t = threadIdx.x;
-    const int k = k0 + (t >> 4);
-    const int mn = mn0 + (t & 15) * 4;
-    v[0] = v[1] = v[2] = v[3] = 0.f;
-    if (k < kend) {
-        const float* q = p + (long long)k * ld + mn;
-        if (vec_ok && mn + 3 < mem) {
-            const float4 f = *reinterpret_cast<const float4*>(q);
-            v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (mn + c < mem) v[c] = q[c];
-                else if (aug && mn + c == mem) v[c] = 1.f;
+                for (int c = 0; c < 4; ++c) if (k + c < kend) v[i][c] = q[c];
             }
         }
     }
 }
-__device__ __forceinline__ void store_mncont(float* s, const float (&v)[4]) {
-    const int t = threadIdx.x;
-    *reinterpret_cast<float4*>(&s[(t >> 4) * LDS_STRIDE + (t & 15) * 4]) = make_float4(v[0], v[1], v[2], v[3]);
+template <int T>
+__device__ __forceinline__ void store_kcont(float* s, const float (&v)[(T * 4 + NT - 1) / NT][4]) {
+    constexpr int NU = (T * 4 + NT - 1) / NT;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const int u = threadIdx.x + i * NT;
+        if (u >= T * 4) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[((u & 3) * 4 + c) * (T + 4) + (u >> 2)] = v[i][c];
+    }
+}
+// mn-contiguous source p[k*ld + mn]: float4 unit u -> k = u / (T/4), mn = 4 (u % (T/4)); mn == mem (only for the
+// augmented operand) reads as 1, mn > mem as 0.
+template <int T>
+__device__ __forceinline__ void fetch_mncont(const float* __restrict__ p, int ld, int mn0, int mem, bool aug, int k0,
+                                             int kend, bool vec_ok, float (&v)[(T * 4 + NT - 1) / NT][4]) {
+    constexpr int NU = (T * 4 + NT - 1) / NT;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const int u = threadIdx.x + i * NT;
+        v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+        if (u >= T * 4) continue;
+        const int k = k0 + u / (T / 4), mn = mn0 + (u % (T / 4)) * 4;
+        if (k < kend) {
+            const float* q = p + (long long)k * ld + mn;
+            if (vec_ok && mn + 3 < mem) {
+                const float4 f = *reinterpret_cast<const float4*>(q);
+                v[i][0] = f.x; v[i][1] = f.y; v[i][2] = f.z; v[i][3] = f.w;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (mn + c < mem) v[i][c] = q[c];
+                    else if (aug && mn + c == mem) v[i][c] = 1.f;
+                }
+            }
+        }
+    }
+}
+template <int T>
+__device__ __forceinline__ void store_mncont(float* s, const float (&v)[(T * 4 + NT - 1) / NT][4]) {
+    constexpr int NU = (T * 4 + NT - 1) / NT;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const int u = threadIdx.x + i * NT;
+        if (u >= T * 4) continue;
+        *reinterpret_cast<float4*>(&s[(u / (T / 4)) * (T + 4) + (u % (T / 4)) * 4]) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+    }
 }
 
-template <bool A_KCONT, bool B_KCONT, int EPI>
+template <bool A_KCONT, bool B_KCONT, int EPI, int WM, int WN>
 __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[BK * LDS_STRIDE];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * LDS_STRIDE];
+    constexpr int BM = 32 * WM, BN = 32 * WN, SA = BM + 4, SB = BN + 4;
+    __shared__ __attribute__((aligned(16))) float As[BK * SA];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * SB];
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s), so give each XCD
     // a CONTIGUOUS run of the linearised (x fastest) tile space: the tiles that share an A row panel / B
     // column panel then hit the same L2 instead of each fetching the panel again (speed only, never
@@ -113,30 +140,30 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
     const bool b_vec = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0) &&
                        (B_KCONT ? (kbeg % 4 == 0) : true);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-    float ra[4], rb[4];
+    float ra[(BM * 4 + NT - 1) / NT][4], rb[(BN * 4 + NT - 1) / NT][4];
     auto fetch = [&](int k0) {
-        if (A_KCONT) fetch_kcont(g.A, g.lda, m0, g.M, k0, kend, a_vec, ra);
-        else fetch_mncont(g.A, g.lda, m0, g.a_mem, EPI == EPI_DW, k0, kend, a_vec, ra);
-        if (B_KCONT) fetch_kcont(g.B, g.ldb, n0, g.N, k0, kend, b_vec, rb);
-        else fetch_mncont(g.B, g.ldb, n0, g.N, false, k0, kend, b_vec, rb);
+        if (A_KCONT) fetch_kcont<BM>(g.A, g.lda, m0, g.M, k0, kend, a_vec, ra);
+        else fetch_mncont<BM>(g.A, g.lda, m0, g.a_mem, EPI == EPI_DW, k0, kend, a_vec, ra);
+        if (B_KCONT) fetch_kcont<BN>(g.B, g.ldb, n0, g.N, k0, kend, b_vec, rb);
+        else fetch_mncont<BN>(g.B, g.ldb, n0, g.N, false, k0, kend, b_vec, rb);
     };
     if (kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();                       // previous tile fully consumed
-        if (A_KCONT) store_kcont(As, ra); else store_mncont(As, ra);
-        if (B_KCONT) store_kcont(Bs, rb); else store_mncont(Bs, rb);
+        if (A_KCONT) store_kcont<BM>(As, ra); else store_mncont<BM>(As, ra);
+        if (B_KCONT) store_kcont<BN>(Bs, rb); else store_mncont<BN>(Bs, rb);
         __syncthreads();
         if (k0 + BK < kend) fetch(k0 + BK);    // in flight under the MFMAs below
-        const float* pa = As + (lane >> 5) * LDS_STRIDE + wm * 32 + (lane & 31);
-        const float* pb = Bs + (lane >> 5) * LDS_STRIDE + wn * 32 + (lane & 31);
+        const float* pa = As + (lane >> 5) * SA + wm * 32 + (lane & 31);
+        const float* pb = Bs + (lane >> 5) * SB + wn * 32 + (lane & 31);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk * LDS_STRIDE], pb[kk * LDS_STRIDE], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk * SA], pb[kk * SB], acc, 0, 0, 0);
         }
     }
     // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -171,19 +198,26 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
     }
 }
 
-template <bool A_KCONT, bool B_KCONT, int EPI>
-static int launch(const GemmArgs& g, int splits, hipStream_t st) {
-    if (g.M <= 0 || g.N <= 0) return VAEK_OK;
+template <bool A_KCONT, bool B_KCONT, int EPI, int WM, int WN>
+static int launch_shape(const GemmArgs& g, int splits, hipStream_t st) {
     ProfScope ps(EPI == EPI_FWD ? "gemm_f32_fwd" : EPI == EPI_REPARAM ? "gemm_f32_fwd_reparam"
                  : EPI == EPI_DX ? "gemm_f32_dx" : "gemm_f32_dw", st);
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
+    dim3 grid((g.N + 32 * WN - 1) / (32 * WN), (g.M + 32 * WM - 1) / (32 * WM), splits);
     if (grid.y > 65535u || grid.z > 65535u) {
         set_error("gemm grid too large (M=%d N=%d splits=%d)", g.M, g.N, splits);
         return VAEK_ERR_INVALID;
     }
-    launch_k(ps, (gemm_f32_kernel<A_KCONT, B_KCONT, EPI>), grid, dim3(NT), 0, st, g);
+    launch_k(ps, (gemm_f32_kernel<A_KCONT, B_KCONT, EPI, WM, WN>), grid, dim3(NT), 0, st, g);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
+}
+
+template <bool A_KCONT, bool B_KCONT, int EPI>
+static int launch(const GemmArgs& g, int splits, hipStream_t st) {
+    if (g.M <= 0 || g.N <= 0) return VAEK_OK;
+    if (g.N <= 32) return launch_shape<A_KCONT, B_KCONT, EPI, 4, 1>(g, splits, st);     // skinny output: 128 x 32
+    if (g.M <= 32) return launch_shape<A_KCONT, B_KCONT, EPI, 1, 4>(g, splits, st);     // skinny M:      32 x 128
+    return launch_shape<A_KCONT, B_KCONT, EPI, 2, 2>(g, splits, st);                    // 64 x 64
 }
 
 int launch_dense_fwd(const float* x, const float* w, const float* b, float* y, int rows, int n_in,
