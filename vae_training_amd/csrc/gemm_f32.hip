@@ -17,7 +17,7 @@ namespace vaek {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int BK = 16, NT = 256;
+constexpr int NT = 256;      // BK (k-tile depth) is a template parameter: 16, or 32 for the streaming skinny shapes
 // Tile shapes: WM x WN waves of 32x32 each (WM * WN = 4): 2x2 = 64x64 for square-ish layers, 4x1 = 128x32
 // for skinny outputs (N <= 32: the latent / data dims of every VAE here), 1x4 = 32x128 for skinny M (the
 // dW|db of an input layer with a handful of features).  With a 64-wide tile a 20-column output keeps half
@@ -38,18 +38,18 @@ struct GemmArgs {
     int k_per_split; long long slab_stride;   // DW
 };
 
-// Operand tile = T (mn) x 16 (k) floats, staged k-major into LDS rows of T + 4 floats.
-// k-contiguous source p[mn*ld + k]: float4 unit u -> row u >> 2, k = 4 (u & 3); U = T*4 units over 256 threads.
-template <int T>
+// Operand tile = T (mn) x BK (k) floats, staged k-major into LDS rows of T + 4 floats.
+// k-contiguous source p[mn*ld + k]: float4 unit u -> row u / (BK/4), k = 4 (u % (BK/4)); T*BK/4 units over 256 threads.
+template <int T, int BK>
 __device__ __forceinline__ void fetch_kcont(const float* __restrict__ p, int ld, int mn0, int MN, int k0, int kend,
-                                            bool vec_ok, float (&v)[(T * 4 + NT - 1) / NT][4]) {
-    constexpr int NU = (T * 4 + NT - 1) / NT;
+                                            bool vec_ok, float (&v)[(T * BK / 4 + NT - 1) / NT][4]) {
+    constexpr int NU = (T * BK / 4 + NT - 1) / NT;
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
         const int u = threadIdx.x + i * NT;
         v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
-        if (u >= T * 4) continue;
-        const int mn = mn0 + (u >> 2), k = k0 + (u & 3) * 4;
+        if (u >= T * BK / 4) continue;
+        const int mn = mn0 + u / (BK / 4), k = k0 + (u % (BK / 4)) * 4;
         if (mn < MN) {
             const float* q = p + (long long)mn * ld + k;
             if (vec_ok && k + 3 < kend) {
@@ -62,28 +62,28 @@ __device__ __forceinline__ void fetch_kcont(const float* __restrict__ p, int ld,
         }
     }
 }
-template <int T>
-__device__ __forceinline__ void store_kcont(float* s, const float (&v)[(T * 4 + NT - 1) / NT][4]) {
-    constexpr int NU = (T * 4 + NT - 1) / NT;
+template <int T, int BK>
+__device__ __forceinline__ void store_kcont(float* s, const float (&v)[(T * BK / 4 + NT - 1) / NT][4]) {
+    constexpr int NU = (T * BK / 4 + NT - 1) / NT;
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
         const int u = threadIdx.x + i * NT;
-        if (u >= T * 4) continue;
+        if (u >= T * BK / 4) continue;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) s[((u & 3) * 4 + c) * (T + 4) + (u >> 2)] = v[i][c];
+        for (int c = 0; c < 4; ++c) s[((u % (BK / 4)) * 4 + c) * (T + 4) + u / (BK / 4)] = v[i][c];
     }
 }
 // mn-contiguous source p[k*ld + mn]: float4 unit u -> k = u / (T/4), mn = 4 (u % (T/4)); mn == mem (only for the
 // augmented operand) reads as 1, mn > mem as 0.
-template <int T>
+template <int T, int BK>
 __device__ __forceinline__ void fetch_mncont(const float* __restrict__ p, int ld, int mn0, int mem, bool aug, int k0,
-                                             int kend, bool vec_ok, float (&v)[(T * 4 + NT - 1) / NT][4]) {
-    constexpr int NU = (T * 4 + NT - 1) / NT;
+                                             int kend, bool vec_ok, float (&v)[(T * BK / 4 + NT - 1) / NT][4]) {
+    constexpr int NU = (T * BK / 4 + NT - 1) / NT;
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
         const int u = threadIdx.x + i * NT;
         v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
-        if (u >= T * 4) continue;
+        if (u >= T * BK / 4) continue;
         const int k = k0 + u / (T / 4), mn = mn0 + (u % (T / 4)) * 4;
         if (k < kend) {
             const float* q = p + (long long)k * ld + mn;
@@ -100,18 +100,18 @@ __device__ __forceinline__ void fetch_mncont(const float* __restrict__ p, int ld
         }
     }
 }
-template <int T>
-__device__ __forceinline__ void store_mncont(float* s, const float (&v)[(T * 4 + NT - 1) / NT][4]) {
-    constexpr int NU = (T * 4 + NT - 1) / NT;
+template <int T, int BK>
+__device__ __forceinline__ void store_mncont(float* s, const float (&v)[(T * BK / 4 + NT - 1) / NT][4]) {
+    constexpr int NU = (T * BK / 4 + NT - 1) / NT;
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
         const int u = threadIdx.x + i * NT;
-        if (u >= T * 4) continue;
+        if (u >= T * BK / 4) continue;
         *reinterpret_cast<float4*>(&s[(u / (T / 4)) * (T + 4) + (u % (T / 4)) * 4]) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
     }
 }
 
-template <bool A_KCONT, bool B_KCONT, int EPI, int WM, int WN>
+template <bool A_KCONT, bool B_KCONT, int EPI, int WM, int WN, int BK>
 __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
     constexpr int BM = 32 * WM, BN = 32 * WN, SA = BM + 4, SB = BN + 4;
     __shared__ __attribute__((aligned(16))) float As[BK * SA];
@@ -145,18 +145,18 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-    float ra[(BM * 4 + NT - 1) / NT][4], rb[(BN * 4 + NT - 1) / NT][4];
+    float ra[(BM * BK / 4 + NT - 1) / NT][4], rb[(BN * BK / 4 + NT - 1) / NT][4];
     auto fetch = [&](int k0) {
-        if (A_KCONT) fetch_kcont<BM>(g.A, g.lda, m0, g.M, k0, kend, a_vec, ra);
-        else fetch_mncont<BM>(g.A, g.lda, m0, g.a_mem, EPI == EPI_DW, k0, kend, a_vec, ra);
-        if (B_KCONT) fetch_kcont<BN>(g.B, g.ldb, n0, g.N, k0, kend, b_vec, rb);
-        else fetch_mncont<BN>(g.B, g.ldb, n0, g.N, false, k0, kend, b_vec, rb);
+        if (A_KCONT) fetch_kcont<BM, BK>(g.A, g.lda, m0, g.M, k0, kend, a_vec, ra);
+        else fetch_mncont<BM, BK>(g.A, g.lda, m0, g.a_mem, EPI == EPI_DW, k0, kend, a_vec, ra);
+        if (B_KCONT) fetch_kcont<BN, BK>(g.B, g.ldb, n0, g.N, k0, kend, b_vec, rb);
+        else fetch_mncont<BN, BK>(g.B, g.ldb, n0, g.N, false, k0, kend, b_vec, rb);
     };
     if (kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();                       // previous tile fully consumed
-        if (A_KCONT) store_kcont<BM>(As, ra); else store_mncont<BM>(As, ra);
-        if (B_KCONT) store_kcont<BN>(Bs, rb); else store_mncont<BN>(Bs, rb);
+        if (A_KCONT) store_kcont<BM, BK>(As, ra); else store_mncont<BM, BK>(As, ra);
+        if (B_KCONT) store_kcont<BN, BK>(Bs, rb); else store_mncont<BN, BK>(Bs, rb);
         __syncthreads();
         if (k0 + BK < kend) fetch(k0 + BK);    // in flight under the MFMAs below
         const float* pa = As + (lane >> 5) * SA + wm * 32 + (lane & 31);
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
     }
 }
 
-template <bool A_KCONT, bool B_KCONT, int EPI, int WM, int WN>
+template <bool A_KCONT, bool B_KCONT, int EPI, int WM, int WN, int BK>
 static int launch_shape(const GemmArgs& g, int splits, hipStream_t st) {
     ProfScope ps(EPI == EPI_FWD ? "gemm_f32_fwd" : EPI == EPI_REPARAM ? "gemm_f32_fwd_reparam"
                  : EPI == EPI_DX ? "gemm_f32_dx" : "gemm_f32_dw", st);
@@ -207,7 +207,7 @@ static int launch_shape(const GemmArgs& g, int splits, hipStream_t st) {
         set_error("gemm grid too large (M=%d N=%d splits=%d)", g.M, g.N, splits);
         return VAEK_ERR_INVALID;
     }
-    launch_k(ps, (gemm_f32_kernel<A_KCONT, B_KCONT, EPI, WM, WN>), grid, dim3(NT), 0, st, g);
+    launch_k(ps, (gemm_f32_kernel<A_KCONT, B_KCONT, EPI, WM, WN, BK>), grid, dim3(NT), 0, st, g);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
 }
@@ -215,9 +215,10 @@ static int launch_shape(const GemmArgs& g, int splits, hipStream_t st) {
 template <bool A_KCONT, bool B_KCONT, int EPI>
 static int launch(const GemmArgs& g, int splits, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return VAEK_OK;
-    if (g.N <= 32) return launch_shape<A_KCONT, B_KCONT, EPI, 4, 1>(g, splits, st);     // skinny output: 128 x 32
-    if (g.M <= 32) return launch_shape<A_KCONT, B_KCONT, EPI, 1, 4>(g, splits, st);     // skinny M:      32 x 128
-    return launch_shape<A_KCONT, B_KCONT, EPI, 2, 2>(g, splits, st);                    // 64 x 64
+    // skinny shapes stream a long K past a small output: a 32-deep k-tile halves their barriers per byte
+    if (g.N <= 32) return launch_shape<A_KCONT, B_KCONT, EPI, 4, 1, 32>(g, splits, st);     // skinny output: 128 x 32
+    if (g.M <= 32) return launch_shape<A_KCONT, B_KCONT, EPI, 1, 4, 32>(g, splits, st);     // skinny M:      32 x 128
+    return launch_shape<A_KCONT, B_KCONT, EPI, 2, 2, 16>(g, splits, st);                    // 64 x 64
 }
 
 int launch_dense_fwd(const float* x, const float* w, const float* b, float* y, int rows, int n_in,
