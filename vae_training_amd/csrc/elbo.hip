@@ -40,19 +40,44 @@ __global__ __launch_bounds__(256) void elbo_kernel(const ElboArgs a) {
     float mse = 0.f, deps = 0.f, musq = 0.f;
     if (r0 < r1) {
         const long long e0 = r0 * a.D, e1 = r1 * a.D;
-        for (long long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
-            const float z = a.z2[e];
-            float xh = a.y_lin[e] + sigma * z;
+        auto elem = [&](long long e, float xv, float yl, float ys, float z, float& d_l, float& d_s) {
+            float xh = yl + sigma * z;
             float sg = 0.f;
-            if (SIG) { sg = sigmoidf_(a.y_sig[e]); xh += sg; }
-            const float r = xh - a.x[e];
+            if (SIG) { sg = sigmoidf_(ys); xh += sg; }
+            const float r = xh - xv;
             const float q = r * r * inv_var;
             mse += 0.5f * q;
             deps += -0.5f * q + 0.5f * sigma * z * r * inv_var;
+            d_l = r * dscale;
+            d_s = SIG ? d_l * sg * (1.f - sg) : 0.f;
+        };
+        // 16-byte path: a split starts at a multiple of 64 rows, so e0 is 16-byte aligned whenever the base
+        // pointers are; the (< 4)-element tail of the last split goes through the scalar loop
+        const bool vec = (e0 % 4 == 0) && (((uintptr_t)a.x | (uintptr_t)a.y_lin | (uintptr_t)a.z2 | (uintptr_t)a.y_sig |
+                                             (uintptr_t)a.d_lin | (uintptr_t)a.d_sig) & 15) == 0;
+        long long ev = e0;
+        if (vec) {
+            ev = e0 + ((e1 - e0) & ~3ll);
+            for (long long e = e0 + 4ll * threadIdx.x; e < ev; e += 4ll * blockDim.x) {
+                const float4 xv = *reinterpret_cast<const float4*>(a.x + e), yl = *reinterpret_cast<const float4*>(a.y_lin + e);
+                const float4 z = *reinterpret_cast<const float4*>(a.z2 + e);
+                float4 ys = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (SIG) ys = *reinterpret_cast<const float4*>(a.y_sig + e);
+                float4 dl, ds;
+                elem(e, xv.x, yl.x, ys.x, z.x, dl.x, ds.x); elem(e + 1, xv.y, yl.y, ys.y, z.y, dl.y, ds.y);
+                elem(e + 2, xv.z, yl.z, ys.z, z.z, dl.z, ds.z); elem(e + 3, xv.w, yl.w, ys.w, z.w, dl.w, ds.w);
+                if (GRADS) {
+                    *reinterpret_cast<float4*>(a.d_lin + e) = dl;
+                    if (SIG) *reinterpret_cast<float4*>(a.d_sig + e) = ds;
+                }
+            }
+        }
+        for (long long e = ev + threadIdx.x; e < e1; e += blockDim.x) {
+            float dl, ds;
+            elem(e, a.x[e], a.y_lin[e], SIG ? a.y_sig[e] : 0.f, a.z2[e], dl, ds);
             if (GRADS) {
-                const float d = r * dscale;
-                a.d_lin[e] = d;
-                if (SIG) a.d_sig[e] = d * sg * (1.f - sg);
+                a.d_lin[e] = dl;
+                if (SIG) a.d_sig[e] = ds;
             }
         }
         const long long l0 = r0 * a.L, l1 = r1 * a.L;
