@@ -346,17 +346,23 @@ def main():
                 roofline["peak_measured"] = eng.measure_peaks()
 
     # ---- auxiliary (never `value`): the same step with FRESH inputs drawn on the device every step, as the
-    # reference's loop does (dataset.get_batch + sample_latent, model.py:221 / vae.py:125-128): one Philox
-    # kernel (vaek_make_batch) in front of the two train-step kernels, all inside the hipGraph
+    # reference's loop does (dataset.get_batch + sample_latent, model.py:221 / vae.py:125-128): the Philox draw of
+    # batch n+1 rides in the finalize launch of step n (vaek_train_step_gen), all inside the hipGraph
     fresh = None
     if world == 1 and graph is not None and w["dataset"] == "linear_gaussian":
         A = torch.randn(w["dd"], w["did"], generator=torch.Generator().manual_seed(2)).to(device).contiguous()
-        xg, z1g, z2g = (torch.empty_like(t) for t in batches[0])
+        assert gsteps % 2 == 0
+        bufs = [tuple(torch.empty_like(t) for t in batches[0]) for _ in range(2)]
+        counter = torch.zeros(2, dtype=torch.int32, device=device)
+        eng.make_batch(0, A, w["dd"], w["did"], w["pad"], 0.0, B_local, seed=7, counter=counter, which=0, out=bufs[0])
+        fresh_n = [0]
 
-        def fresh_step():
-            eng.make_batch(0, A, w["dd"], w["did"], w["pad"], 0.0, B_local, seed=7, step_dev=step_dev, tag=0, out=(xg, z1g, z2g))
-            eng.train_step(params, grads, m, v, step_dev, xg, z1g, z2g, lr)
-        for _ in range(3):
+        def fresh_step():       # train on batch n, draw batch n+1 in the finalize launch (vaek_train_step_gen, trainer.GraphLoop)
+            n = fresh_n[0]
+            eng.train_step_gen(params, grads, m, v, step_dev, bufs[n % 2], lr, 0, A, w["dd"], w["did"], w["pad"], 0.0,
+                               bufs[(n + 1) % 2], 7, counter, (n + 1) % 2)
+            fresh_n[0] = n + 1
+        for _ in range(4):
             fresh_step()
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
@@ -375,7 +381,8 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
         fresh = {"samples_per_s": B_local * nrep * gsteps / dt, "us_per_step": dt / (nrep * gsteps) * 1e6,
-                 "note": "inputs generated on the device each step (Philox kernel) instead of pre-resident batches"}
+                 "note": "inputs drawn on the device each step (Philox work items in the finalize launch of the step before: "
+                         "vaek_train_step_gen) instead of pre-resident batches"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

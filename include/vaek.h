@@ -193,6 +193,24 @@ int vaek_comm_status(vaek_ctx* ctx, int32_t* timed_out);
 int vaek_make_batch(vaek_ctx* ctx, int32_t kind, const float* A, int32_t dd, int32_t did, int32_t pad, float var_added,
                     float* x, float* z1, float* z2, int32_t rows, int64_t row0, uint64_t seed,
                     const int32_t* step_dev, uint32_t step_host, uint32_t tag, void* stream);
+/* The same draw for a loop that generates batch n+1 while step n trains (trainer.GraphLoop): the step is
+ * counter[which] and the kernel ITSELF stores counter[which ^ 1] = step + 1 for the next launch, so a captured
+ * launch needs no host argument and does not touch the Adam step counter a concurrently running train step is
+ * incrementing.  The caller alternates `which` (0, 1, 0, ...) from launch to launch -- with two batch buffers that
+ * is the buffer index -- and initialises counter[first which] to the first step.  Bit-identical to
+ * vaek_make_batch(step_host = counter[which]). */
+int vaek_make_batch_next(vaek_ctx* ctx, int32_t kind, const float* A, int32_t dd, int32_t did, int32_t pad, float var_added,
+                         float* x, float* z1, float* z2, int32_t rows, int64_t row0, uint64_t seed,
+                         int32_t* counter /* device int32[2] */, int32_t which, uint32_t tag, void* stream);
+/* vaek_train_step on (x, z1, z2) AND vaek_make_batch_next into (x_next, z1_next, z2_next) -- the loop body of
+ * model.py:221-222 with the draw for step n+1 taken off the critical path.  On the fused path the generator's work
+ * items ride in the finalize launch (which by itself occupies 9 of 256 CUs): still two launches per step, one
+ * stream, no cross-queue dependency.  Elsewhere it is the two calls back to back.  Results are bit-identical to the
+ * separate calls.  The next batch has ctx.batch rows and must not alias the current one. */
+int vaek_train_step_gen(vaek_ctx* ctx, float* params, float* grads, float* m, float* v, int32_t* step_dev, const float* x,
+                        const float* z1, const float* z2, float lr, void* workspace, int32_t kind, const float* A, int32_t dd,
+                        int32_t did, int32_t pad, float var_added, float* x_next, float* z1_next, float* z2_next, int64_t row0,
+                        uint64_t seed, int32_t* counter, int32_t which, uint32_t tag, void* stream);
 /* n standard normals and/or the raw Philox words they came from (block b = counter (b_lo, b_hi, step, tag)). */
 int vaek_rng_fill(vaek_ctx* ctx, float* normals, uint32_t* bits, int64_t n, uint64_t seed, uint32_t step, uint32_t tag,
                   void* stream);

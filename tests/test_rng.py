@@ -93,12 +93,80 @@ def test_graph_loop_equals_eager_steps(tmp_path):
         return VAEModel(dirname=str(tmp_path), num_batches=10, num_epochs=1, batch_size=100, learning_rate=1e-3, layer_sizes="",
                         encoder_layer_sizes="", state_dict=None, data_fn=None, epsilon=-1.0, tqdm=False, dataset=ds,
                         latent_dimension=20, tunable_decoder_var=True, dataset_name="linear_gaussian")
-    a, b = build(), build()
-    la, lb = GraphLoop(a, steps_per_graph=8, seed=5), GraphLoop(b, steps_per_graph=8, seed=5)
-    la.run(30)                       # 2 eager warm-ups + 3 replays of 8 + 4 eager
-    for _ in range(30):
-        lb._one()
+    a, b, c = build(), build(), build()
+    la, lb = GraphLoop(a, steps_per_graph=8, seed=5), GraphLoop(b, steps_per_graph=8, seed=5, pipeline=False)
+    lc = GraphLoop(c, steps_per_graph=8, seed=5, pipeline=False)
+    assert la.pipeline and len(la.bufs) == 2 and len(lb.bufs) == 1
+    la.run(31)                       # pipelined: 2 eager warm-ups + 3 replays of 8 + 5 eager
+    la.run(12)                       # odd step count so far: one eager step to regain buffer parity, a replay, 3 eager
+    lc.run(43)                       # unpipelined graph
+    for _ in range(43):
+        lb._one()                    # unpipelined, step by step: make_batch(step_dev) + train_step
     torch.cuda.synchronize()
-    assert a.optimizer.state.step == 30 == int(a.optimizer.state.step_dev.item()) == int(b.optimizer.state.step_dev.item())
-    assert torch.equal(a.model.flat, b.model.flat) and torch.equal(la.losses(), lb.losses())
-    assert la.losses().numel() == 30 and bool(torch.isfinite(la.losses()).all())
+    assert a.optimizer.state.step == 43 == int(a.optimizer.state.step_dev.item()) == int(b.optimizer.state.step_dev.item())
+    assert la.counter.tolist() == [44, 43]         # the last two draws (batches 42, 43) each left "my step + 1" in the other slot
+    for m_, l_ in ((a, la), (c, lc)):
+        assert torch.equal(m_.model.flat, b.model.flat) and torch.equal(l_.losses(), lb.losses())
+    assert la.losses().numel() == 43 and bool(torch.isfinite(la.losses()).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [1, 100, 65536])
+def test_make_batch_next_is_make_batch_with_a_self_advancing_step(rows):
+    """vaek_make_batch_next draws from counter[which] and stores counter[which ^ 1] = step + 1 -- any grid size."""
+    from vae_training_amd.engine import Engine
+    eng = Engine(rows, 12, 20)
+    A = torch.randn(3, 3, device="cuda")
+    counter = torch.tensor([-1, 7], dtype=torch.int32, device="cuda")
+    for k in range(4):
+        got = eng.make_batch(0, A, 3, 3, 9, 0.25, rows, 11, counter=counter, which=(k + 1) % 2, tag=3, row0=5)
+        want = eng.make_batch(0, A, 3, 3, 9, 0.25, rows, 11, step=7 + k, tag=3, row0=5)
+        assert all(torch.equal(g, w) for g, w in zip(got, want))
+        assert int(counter[k % 2]) == 8 + k and int(counter[(k + 1) % 2]) == 7 + k
+    with pytest.raises(Exception, match="invalid"):
+        eng.make_batch(0, A, 3, 3, 9, 0.25, rows, 11, counter=counter, which=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,hidden,B", [("linear_gaussian", (), 1000), ("linear_gaussian", (), 65536), ("sigmoid", (), 300),
+                                            ("sphere", (64,), 500)])
+def test_train_step_gen_is_make_batch_next_plus_train_step(kind, hidden, B):
+    """vaek_train_step_gen (next batch drawn by spare blocks of the finalize launch on the fused path; two launches
+    back to back on the layer-by-layer path) == vaek_make_batch + vaek_train_step, bit for bit, over several steps."""
+    from vae_training_amd.engine import Engine
+    dd, pad = 3, (9 if kind == "linear_gaussian" else 3)
+    D = dd + pad + (1 if kind == "sigmoid" else 0)
+    L = 20 if kind == "linear_gaussian" else 6
+    k = {"linear_gaussian": 0, "sigmoid": 1, "sphere": 2}[kind]
+    A = torch.randn(3, 3, device="cuda") if k == 0 else torch.randn(3, device="cuda")
+    eng = Engine(B, D, L, hidden, hidden, -1.0, True, kind == "sigmoid")
+    assert bool(eng.fused) == (hidden == ())
+    torch.manual_seed(0)
+    p0 = torch.randn(eng.P, device="cuda") * 0.3
+
+    def state():
+        return [p0.clone(), eng.new_flat(eng.grad_len), eng.new_flat(), eng.new_flat(), torch.zeros(1, dtype=torch.int32, device="cuda")]
+    seed, var = 77, 0.25
+    # (a) separate calls, host step
+    sa = state()
+    losses_a = []
+    for n in range(5):
+        x, z1, z2 = eng.make_batch(k, A, dd, 3, pad, var, B, seed, step=n, tag=1, row0=10)
+        eng.train_step(*sa, x, z1, z2, 1e-3)
+        losses_a.append(sa[1][eng.P].clone())
+    # (b) fused generator
+    sb = state()
+    counter = torch.tensor([0, 0], dtype=torch.int32, device="cuda")
+    bufs = [eng.make_batch(k, A, dd, 3, pad, var, B, seed, counter=counter, which=0, tag=1, row0=10),
+            tuple(torch.empty_like(t) for t in (x, z1, z2))]
+    losses_b = []
+    for n in range(5):
+        eng.train_step_gen(*sb, bufs[n % 2], 1e-3, k, A, dd, 3, pad, var, bufs[(n + 1) % 2], seed, counter, (n + 1) % 2, tag=1, row0=10)
+        losses_b.append(sb[1][eng.P].clone())
+    torch.cuda.synchronize()
+    assert counter.tolist() == [6, 5] and int(sb[4]) == 5
+    assert torch.equal(torch.stack(losses_a), torch.stack(losses_b))
+    for ta, tb in zip(sa[:4], sb[:4]):
+        assert torch.equal(ta, tb)
+    with pytest.raises(Exception, match="alias"):
+        eng.train_step_gen(*sb, bufs[0], 1e-3, k, A, dd, 3, pad, var, bufs[0], seed, counter, 0, tag=1, row0=10)

@@ -23,7 +23,9 @@ for B in (100, 65536):
         m.train_one_batch(m.dataset.get_batch(B))
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"B={B:6d} drop-in python loop : {dt / n * 1e6:8.1f} us/step  {B * n / dt:14.0f} samples/s")
-    m = build(B); loop = GraphLoop(m, steps_per_graph=50)
-    loop.run(200); torch.cuda.synchronize(); t0 = time.perf_counter(); n = 20000
-    loop.run(n); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"B={B:6d} hipGraph loop (K7 rng): {dt / n * 1e6:8.1f} us/step  {B * n / dt:14.0f} samples/s  final loss {float(loop.losses()[-1]):.4f}")
+    for pipe in (False, True):
+        m = build(B); loop = GraphLoop(m, steps_per_graph=50, pipeline=pipe)
+        loop.run(200); torch.cuda.synchronize(); t0 = time.perf_counter(); n = 20000
+        loop.run(n); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"B={B:6d} hipGraph loop (K7 rng, pipeline={pipe!s:5}): {dt / n * 1e6:8.1f} us/step  {B * n / dt:14.0f} samples/s  "
+              f"final loss {float(loop.losses()[-1]):.4f}")

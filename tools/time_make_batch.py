@@ -8,11 +8,10 @@ for B in (100, 65536):
     eng = Engine(B, 12, 20)
     k, A, dd, did, pad, var = ds.device_spec()
     out = eng.make_batch(k, A, dd, did, pad, var, B, 1, step=1)
-    eng.profile_begin(1024)
-    for i in range(100):
-        eng.make_batch(k, A, dd, did, pad, var, B, 1, step=i, out=out)
-        eng.make_batch(k, A, dd, did, pad, var, B, 1, step=i, out=(None, out[1], out[2]))
-        eng.make_batch(k, A, dd, did, pad, var, B, 1, step=i, out=(out[0], None, None))
-    torch.cuda.synchronize()
-    r = eng.profile_report()["make_batch"]
-    print(B, "avg over x+z / z-only / x-only launches:", round(r["total_ms"] / r["count"] * 1e3, 2), "us")
+    for name, o in (("x+z", out), ("z only", (None, out[1], out[2])), ("x only", (out[0], None, None))):
+        eng.profile_begin(1024)
+        for i in range(100):
+            eng.make_batch(k, A, dd, did, pad, var, B, 1, step=i, out=o)
+        torch.cuda.synchronize()
+        r = eng.profile_report()["make_batch"]
+        print(B, name, round(r["total_ms"] / r["count"] * 1e3, 2), "us")

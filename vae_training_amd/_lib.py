@@ -63,6 +63,10 @@ SIGNATURES = {
     "vaek_comm_allreduce": (C.c_int, [_vp, _vp, _i64, _vp]),
     "vaek_make_batch": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _i32, _i64, C.c_uint64, _vp,
                                   C.c_uint32, C.c_uint32, _vp]),
+    "vaek_make_batch_next": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _i32, _i64, C.c_uint64, _vp,
+                                       _i32, C.c_uint32, _vp]),
+    "vaek_train_step_gen": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _vp, _i32, _i32, _i32, _f32,
+                                      _vp, _vp, _vp, _i64, C.c_uint64, _vp, _i32, C.c_uint32, _vp]),
     "vaek_rng_fill": (C.c_int, [_vp, _vp, _vp, _i64, C.c_uint64, C.c_uint32, C.c_uint32, _vp]),
     "vaek_set_loss_history": (C.c_int, [_vp, _vp, _i64]),
     "vaek_microbench_copy": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),

@@ -457,6 +457,35 @@ int vaek_train_step(vaek_ctx* ctx, float* params, float* grads, float* m, float*
     return generic_finalize(ctx, params, grads, params, m, v, step_dev, lr, workspace, st);
 }
 
+// Train on the batch (x, z1, z2) AND draw the next one (x_next, z1_next, z2_next; none may alias the current batch)
+// from the self-advancing generator counter: see include/vaek.h.
+int vaek_train_step_gen(vaek_ctx* ctx, float* params, float* grads, float* m, float* v, int32_t* step_dev, const float* x,
+                        const float* z1, const float* z2, float lr, void* workspace, int32_t kind, const float* A, int32_t dd,
+                        int32_t did, int32_t pad, float var_added, float* x_next, float* z1_next, float* z2_next, int64_t row0,
+                        uint64_t seed, int32_t* counter, int32_t which, uint32_t tag, void* stream) {
+    ProfBind pb(ctx);
+    if (!ctx || !params || !grads || !m || !v || !step_dev || !x || !z1 || !z2 || !x_next || !z1_next || !z2_next || !counter) {
+        set_error("vaek_train_step_gen: null argument");
+        return VAEK_ERR_INVALID;
+    }
+    if (x_next == x || z1_next == z1 || z2_next == z2) {
+        set_error("vaek_train_step_gen: the next batch must not alias the current one");
+        return VAEK_ERR_INVALID;
+    }
+    BatchArgs gen;
+    int rc = make_batch_args(ctx, kind, A, dd, did, pad, var_added, x_next, z1_next, z2_next, ctx->B, row0, seed, nullptr, 0, counter,
+                             which, tag, &gen);
+    if (rc) return rc;
+    if ((rc = check_ws(ctx, workspace))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const bool comm_ok = ctx->cfg.world == 1 || ctx->comm.ready;
+    if (ctx->fused && comm_ok)
+        return fused_train_step(ctx, params, grads, m, v, step_dev, x, z1, z2, lr, true, ctx->cfg.world > 1, workspace, st, &gen);
+    // layer-by-layer path: the same two operations as separate launches on the one stream
+    if ((rc = make_batch_launch(ctx, gen, st))) return rc;
+    return vaek_train_step(ctx, params, grads, m, v, step_dev, x, z1, z2, lr, workspace, stream);
+}
+
 // buckets in the order the backward pass completes them: Decoder (last layer first), SigDecoder, Encoder, tail
 static void bucket_list(const vaek_ctx* c, std::vector<std::pair<int64_t, int64_t>>& out) {
     out.clear();

@@ -18,6 +18,7 @@
 //   fused_finalize_kernel fixed-order sum of the partial rows, the closed-form KL / log-variance
 //       terms, loss/Dkl/mse means, and Adam (flax.optim.Adam.apply_gradient, networks.py:100).
 #include "comm_dev.h"
+#include "rng_dev.h"
 #include "vaek_internal.h"
 
 namespace vaek {
@@ -407,7 +408,7 @@ __device__ __forceinline__ void adam_apply_f(float& p, float g, float& m, float&
 // scalar sums, which need each other) always sit together in block 0.  1024 threads = 64 outputs x
 // 16 row groups; each thread issues its (up to 16 x FIN_UNROLL) independent loads back to back.
 constexpr int FIN_Q = 16;
-__global__ __launch_bounds__(1024) void fused_finalize_kernel(const FusedFinArgs a) {
+__device__ __forceinline__ void fused_finalize_block(const FusedFinArgs& a) {
     __shared__ float part[FIN_Q][64];
     __shared__ float sums[64];
     const int n = a.P + kExtra;
@@ -481,6 +482,23 @@ __global__ __launch_bounds__(1024) void fused_finalize_kernel(const FusedFinArgs
     }
 }
 
+__global__ __launch_bounds__(1024) void fused_finalize_kernel(const FusedFinArgs a) { fused_finalize_block(a); }
+
+// vaek_train_step_gen: the finalize needs ceil((P+4)/64) blocks -- 9 of 256 CUs at the metric's size -- and is a
+// chain of two dependent memory round trips.  The draw of the NEXT step's batch does not depend on the weights, so
+// it rides in the same launch: blocks [0, nfin) finalize (dispatched first: they are the critical path), the rest
+// are K7's work items, 1024 per block.  One launch, one stream: no cross-queue dependency anywhere.
+// Measured (tools/time_step_gen.py): at B = 100 the step loses a whole launch (15.7 -> 12.7 us in the graph loop);
+// at B = 65 536 the draw itself is ALU-bound (Philox + Box-Muller, ~3 us of issue over the whole chip) and the
+// combined launch takes 10.9 us against 4.5 + 7.6 apart -- a wash there.  Tried and slower: a resident-sized
+// generator grid walking contiguous chunks (13.4-14.4 us).
+__global__ __launch_bounds__(1024) void fused_finalize_gen_kernel(const FusedFinArgs a, const BatchArgs b, const int nfin) {
+    if ((int)blockIdx.x < nfin) { fused_finalize_block(a); return; }
+    const unsigned step = make_batch_step(b);
+    make_batch_items(b, step, (long long)(blockIdx.x - nfin) * 1024 + threadIdx.x);
+    make_batch_advance(b, step, (int)blockIdx.x == nfin && threadIdx.x == 0);
+}
+
 // ---- host side ------------------------------------------------------------------------------------
 typedef void (*FusedKernel)(const float*, const FusedArgs);
 struct FusedVariant { int dp, lp, sig, tile, exact; FusedKernel fn; size_t lds_bytes; };
@@ -535,7 +553,7 @@ size_t fused_workspace_bytes(const vaek_ctx* c) {
 
 int fused_train_step(vaek_ctx* c, float* params, float* grads, float* m, float* v, int32_t* step_dev,
                      const float* x, const float* z1, const float* z2, float lr, bool apply_adam, bool exchange,
-                     void* ws, hipStream_t st) {
+                     void* ws, hipStream_t st, const BatchArgs* gen) {
     const FusedVariant* var = pick_variant(c);
     if (!var) { set_error("fused path not available for this configuration"); return VAEK_ERR_INVALID; }
     static thread_local const void* lds_set[sizeof(kVariants) / sizeof(kVariants[0])] = {};
@@ -575,9 +593,14 @@ int fused_train_step(vaek_ctx* c, float* params, float* grads, float* m, float* 
     f.comm = CommDev{};
     if (exchange) f.comm = comm_dev(c, 0);
     f.loss_hist = (apply_adam && (exchange || c->cfg.world == 1)) ? c->loss_hist : nullptr; f.loss_hist_cap = c->loss_hist_cap;
-    {
+    const int nfin = (int)((c->P + kExtra + 63) / 64);
+    if (gen) {
+        ProfScope ps("fused_finalize_adam_gen", st);
+        const long long ngen = (make_batch_item_count(*gen) + 1023) / 1024;
+        launch_k(ps, fused_finalize_gen_kernel, dim3((unsigned)(nfin + ngen)), dim3(1024), 0, st, f, *gen, nfin);
+    } else {
         ProfScope ps(apply_adam ? "fused_finalize_adam" : "fused_finalize", st);
-        launch_k(ps, fused_finalize_kernel, dim3((unsigned)((c->P + kExtra + 63) / 64)), dim3(1024), 0, st, f);
+        launch_k(ps, fused_finalize_kernel, dim3((unsigned)nfin), dim3(1024), 0, st, f);
     }
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;

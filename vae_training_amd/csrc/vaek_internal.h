@@ -189,11 +189,28 @@ struct FusedArgs {
 bool fused_mfma_supported(const vaek_ctx* c);
 int fused_mfma_launch(const vaek_ctx* c, const float* params, const void* fused_args, int grid, hipStream_t st);
 
+// ---- rng.hip ------------------------------------------------------------------------------
+struct BatchArgs {
+    int kind;                   // 0 linear_gaussian, 1 sigmoid, 2 sphere
+    const float* A;             // linear: [dd][did] row-major; sigmoid: [dd]; sphere: unused
+    int dd, did, pad; float noise_std;
+    float* x; float* z1; float* z2;
+    int rows; long long row0; int D, L;
+    unsigned long long seed; const int32_t* step_dev; unsigned step_host, tag;
+    int32_t* counter; int which; // make_batch_next: step = counter[which]; the launch stores counter[which ^ 1] = step + 1
+};
+// validates the arguments of vaek_make_batch* and fills `out`
+int make_batch_args(vaek_ctx* ctx, int32_t kind, const float* A, int32_t dd, int32_t did, int32_t pad, float var_added,
+                    float* x, float* z1, float* z2, int32_t rows, int64_t row0, uint64_t seed, const int32_t* step_dev,
+                    uint32_t step_host, int32_t* counter, int32_t which, uint32_t tag, BatchArgs* out);
+int make_batch_launch(vaek_ctx* ctx, const BatchArgs& a, hipStream_t st);
+
 // ---- fused_small.hip ----------------------------------------------------------------------
 bool fused_supported(const vaek_ctx* c);
 size_t fused_workspace_bytes(const vaek_ctx* c);
+// gen != nullptr: the finalize launch carries extra blocks that draw the NEXT step's batch (vaek_train_step_gen)
 int fused_train_step(vaek_ctx* c, float* params, float* grads, float* m, float* v, int32_t* step_dev,
                      const float* x, const float* z1, const float* z2, float lr, bool apply_adam, bool exchange,
-                     void* ws, hipStream_t st);
+                     void* ws, hipStream_t st, const BatchArgs* gen = nullptr);
 
 }  // namespace vaek

@@ -58,6 +58,7 @@ class Engine:
         cfg.dtype = {"f32": _lib.VAEK_F32, "bf16": _lib.VAEK_BF16}[dtype]
         cfg.device = self.device.index
         cfg.world, cfg.rank, cfg.global_batch = int(world), int(rank), int(global_batch)
+        self.world, self.rank = int(world), int(rank)
         cfg.force_generic = int(bool(force_generic))
         cfg.reserved[0] = {"auto": 0, "mfma": 0, "valu": 1}[fused_impl]      # which fused linear-VAE kernel
         self.cfg = cfg
@@ -110,6 +111,17 @@ class Engine:
         _lib.check(self.lib.vaek_train_step(self.h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(step_dev),
                                             _ptr(x), _ptr(z1), _ptr(z2), float(lr), _ptr(self.workspace), _stream()))
 
+    def train_step_gen(self, params, grads, m, v, step_dev, cur, lr, kind, A, dd, did, pad, var_added, nxt, seed, counter,
+                       which, tag=0, row0=0):
+        """vaek_train_step on the batch `cur` = (x, z1, z2) and the draw of the next batch into `nxt` (its step is
+        counter[which], and counter[which ^ 1] = step + 1 is stored) -- on the fused path inside the finalize launch."""
+        assert counter.dtype == torch.int32 and counter.numel() == 2 and counter.is_cuda
+        _lib.check(self.lib.vaek_train_step_gen(self.h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(step_dev),
+                                                _ptr(cur[0]), _ptr(cur[1]), _ptr(cur[2]), float(lr), _ptr(self.workspace),
+                                                int(kind), _ptr(A), int(dd), int(did), int(pad), float(var_added),
+                                                _ptr(nxt[0]), _ptr(nxt[1]), _ptr(nxt[2]), int(row0), int(seed) & (2**64 - 1),
+                                                _ptr(counter), int(which), int(tag), _stream()))
+
     def grads_only(self, params, grads, step_dev, x, z1, z2):
         _lib.check(self.lib.vaek_train_step_grads_only(self.h, _ptr(params), _ptr(grads), _ptr(step_dev), _ptr(x),
                                                        _ptr(z1), _ptr(z2), _ptr(self.workspace), _stream()))
@@ -152,8 +164,9 @@ class Engine:
 
     # ---- on-device inputs (K7) and the loss ring ------------------------------------------------
     def make_batch(self, kind, A, dd, did, pad, var_added, rows, seed, step_dev=None, step=0, tag=0, row0=0,
-                   want_x=True, want_z=True, out=None):
-        """x[rows,D] (or None), z1[rows,L], z2[rows,D] drawn by libvaek's Philox kernel."""
+                   want_x=True, want_z=True, out=None, counter=None, which=0):
+        """x[rows,D] (or None), z1[rows,L], z2[rows,D] drawn by libvaek's Philox kernel.  With `counter` (device
+        int32[2]) the step is counter[which] and the kernel stores counter[which ^ 1] = step + 1 (vaek_make_batch_next)."""
         if out is None:
             Dx = dd + pad + (1 if kind == 1 else 0)
             x = torch.empty(rows, Dx, dtype=torch.float32, device=self.device) if want_x else None
@@ -161,6 +174,12 @@ class Engine:
             z2 = torch.empty(rows, self.D, dtype=torch.float32, device=self.device) if want_z else None
         else:
             x, z1, z2 = out
+        if counter is not None:
+            assert counter.dtype == torch.int32 and counter.numel() == 2 and counter.is_cuda
+            _lib.check(self.lib.vaek_make_batch_next(self.h, int(kind), _ptr(A), int(dd), int(did), int(pad), float(var_added),
+                                                     _ptr(x), _ptr(z1), _ptr(z2), int(rows), int(row0),
+                                                     int(seed) & (2**64 - 1), _ptr(counter), int(which), int(tag), _stream()))
+            return x, z1, z2
         _lib.check(self.lib.vaek_make_batch(self.h, int(kind), _ptr(A), int(dd), int(did), int(pad), float(var_added),
                                             _ptr(x), _ptr(z1), _ptr(z2), int(rows), int(row0), int(seed) & (2**64 - 1),
                                             _ptr(step_dev), int(step), int(tag), _stream()))

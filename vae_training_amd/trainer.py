@@ -1,47 +1,85 @@
 """Graph-captured training loop: the reference's hot loop (model.py:221-222 -- get_batch, sample_latent,
 train_step, append loss) with NOTHING on the host per step.
 
-Per step three launches -- vaek_make_batch (Philox dataset + latent draw, K7), and the two kernels of
-vaek_train_step -- are captured G at a time into a hipGraph; the Adam step counter, the RNG step and
-the loss ring buffer all live on the device, so replays need no arguments.  At the reference's own
-batch size (100) the per-step Python of the drop-in path (~50 us) is 3-4x the GPU time; this loop
-removes it without changing what a step computes."""
+The launches of a step -- the Philox dataset + latent draw (K7) and the two kernels of vaek_train_step --
+are captured G steps at a time into a hipGraph; the Adam step counter, the RNG step and the loss ring
+buffer all live on the device, so replays need no arguments.  At the reference's own batch size (100)
+the per-step Python of the drop-in path (~50 us) is 3-4x the GPU time; this loop removes it without
+changing what a step computes.
+
+`pipeline=True` (default) draws batch n+1 WHILE step n trains (vaek_train_step_gen): the draw does not
+depend on the weights, so its work items ride in the finalize launch of step n -- which by itself keeps
+9 of 256 CUs busy -- and write the other of two batch buffers.  The draw takes its step from a counter pair the
+generator advances itself, not from the Adam step counter that same launch is incrementing.  Same
+counters, same Philox streams: losses and parameters are bit-identical to `pipeline=False`
+(vaek_make_batch, then vaek_train_step).  (A second stream / parallel graph branch for the draw was
+measured first: cross-branch edges of a hipGraph cost far more than the 7 us they were meant to hide.)"""
 from __future__ import annotations
 
 import torch
 
 
 class GraphLoop:
-    def __init__(self, vae_model, steps_per_graph=50, seed=None, loss_capacity=1 << 20):
+    def __init__(self, vae_model, steps_per_graph=50, seed=None, loss_capacity=1 << 20, pipeline=True):
         m = vae_model
         self.m = m
         ds = m.dataset
         self.kind, self.A, self.dd, self.did, self.pad, self.var = ds.device_spec()
         self.B = m.batch_size
         self.eng = m.model.module.engine(self.B, m.optimizer.global_batch)
+        ex = m.optimizer.exchange
+        if self.eng.world > 1 and not (ex is not None and ex.in_library):
+            raise RuntimeError("GraphLoop under data parallelism needs the in-library P2P exchange (GradExchange mode 'p2p'): "
+                               "an RCCL all-reduce between the two halves of the step is not captured")
+        self.row0 = self.eng.rank * self.B           # ranks draw disjoint rows of the global batch
         self.seed = (ds.key[0] ^ ds.key[1] ^ m.key[1]) if seed is None else seed
+        self.pipeline = bool(pipeline)
         self.G = int(steps_per_graph)
+        if self.pipeline and self.G % 2:
+            self.G += 1                              # two batch buffers: a replay must start on the parity it was captured on
         dev = self.eng.device
-        self.x = torch.empty(self.B, self.eng.D, dtype=torch.float32, device=dev)
-        self.z1 = torch.empty(self.B, self.eng.L, dtype=torch.float32, device=dev)
-        self.z2 = torch.empty(self.B, self.eng.D, dtype=torch.float32, device=dev)
+
+        def bufs():
+            return (torch.empty(self.B, self.eng.D, dtype=torch.float32, device=dev),
+                    torch.empty(self.B, self.eng.L, dtype=torch.float32, device=dev),
+                    torch.empty(self.B, self.eng.D, dtype=torch.float32, device=dev))
+        self.bufs = [bufs() for _ in range(2 if self.pipeline else 1)]
         self.loss_ring = torch.zeros(loss_capacity, dtype=torch.float32, device=dev)
         self.eng.set_loss_history(self.loss_ring)
         self.graph = None
+        self.graph_parity = 0
         self.steps_done_at_attach = m.optimizer.state.step
+        if self.pipeline:
+            n = m.optimizer.state.step
+            # the generator's own step counter, a pair used alternately (vaek_make_batch_next): the draw of batch k
+            # reads counter[k % 2] and stores k + 1 into the other slot.  Invariant between steps: the batch of the
+            # next step n is in bufs[n % 2] and counter[(n + 1) % 2] == n + 1.
+            self.counter = torch.tensor([n, n], dtype=torch.int32, device=dev)
+            self._make(self.bufs[n % 2], counter=self.counter, which=n % 2)
+
+    def _make(self, out, **kw):
+        self.eng.make_batch(self.kind, self.A, self.dd, self.did, self.pad, self.var, self.B, self.seed,
+                            tag=0, row0=self.row0, out=out, **kw)
 
     def _one(self):
         st = self.m.optimizer.state
-        self.eng.make_batch(self.kind, self.A, self.dd, self.did, self.pad, self.var, self.B, self.seed,
-                            step_dev=st.step_dev, tag=0, out=(self.x, self.z1, self.z2))
-        self.eng.train_step(self.m.model.flat, st.grads, st.m, st.v, st.step_dev, self.x, self.z1, self.z2,
-                            self.m.optimizer.optimizer_def.learning_rate)
+        lr = self.m.optimizer.optimizer_def.learning_rate
+        if self.pipeline:
+            n = st.step
+            self.eng.train_step_gen(self.m.model.flat, st.grads, st.m, st.v, st.step_dev, self.bufs[n % 2], lr,
+                                    self.kind, self.A, self.dd, self.did, self.pad, self.var, self.bufs[(n + 1) % 2],
+                                    self.seed, self.counter, (n + 1) % 2, tag=0, row0=self.row0)
+        else:
+            x, z1, z2 = self.bufs[0]
+            self._make(self.bufs[0], step_dev=st.step_dev)
+            self.eng.train_step(self.m.model.flat, st.grads, st.m, st.v, st.step_dev, x, z1, z2, lr)
         st.step += 1
 
     def _capture(self):
         for _ in range(2):                       # warm-up outside capture (lazy kernel attributes etc.)
             self._one()
         torch.cuda.synchronize()
+        self.graph_parity = self.m.optimizer.state.step % 2
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -60,10 +98,15 @@ class GraphLoop:
         done = 0
         if self.graph is None and n_steps >= self.G + 2:
             done += self._capture()
-        while self.graph is not None and n_steps - done >= self.G:
-            self.graph.replay()
-            self.m.optimizer.state.step += self.G
-            done += self.G
+        st = self.m.optimizer.state
+        if self.graph is not None and self.pipeline and n_steps - done > self.G and st.step % 2 != self.graph_parity:
+            self._one()                          # back onto the buffer parity the graph was captured on
+            done += 1
+        if self.graph is not None and (not self.pipeline or st.step % 2 == self.graph_parity):
+            while n_steps - done >= self.G:
+                self.graph.replay()
+                st.step += self.G
+                done += self.G
         for _ in range(n_steps - done):
             self._one()
 
