@@ -77,3 +77,59 @@ def test_p2p_exchange_inside_finalize(world):
     for rank, lerr, perr, same, timed_out, tb in res:
         assert tb is None, tb
         assert lerr <= 1e-5 and perr <= 0.02 * 1e-3 and same and not timed_out, (rank, lerr, perr, same, timed_out)
+
+
+def _silent_peer_worker(rank, world, port, q):
+    try:
+        import ctypes as C
+        import time
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        from vae_training_amd import _lib
+        from vae_training_amd.engine import Engine
+        from vae_training_amd.parallel import GradExchange
+        eng = Engine(256, 12, 20, (), (), -1.0, True, False, world=world, rank=rank, global_batch=512)
+        ex = GradExchange(eng, dist, mode="p2p")
+        assert ex.in_library
+        out = None
+        if rank == 0:                      # rank 1 never joins these two exchanges
+            buf = torch.ones(64, device="cuda")
+            times = []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                _lib.check(eng.lib.vaek_comm_allreduce(eng.h, C.c_void_p(buf.data_ptr()), 64,
+                                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+            out = (times, ex.timed_out())
+        dist.barrier()
+        q.put((rank, out, None))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, None, traceback.format_exc()))
+
+
+def test_p2p_exchange_gives_up_on_a_silent_peer_and_then_fails_fast():
+    """A peer that never stores its granules must cost seconds, not minutes: the first exchange gives up within the
+    bounded spin (comm_dev.h: kSpinLimit), raises the status word the host polls before falling back to RCCL
+    (parallel.GradExchange.timed_out), and later exchanges on that rank do not wait at all."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_silent_peer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict()
+    for _ in procs:
+        rank, out, tb = q.get(timeout=240)
+        assert tb is None, tb
+        res[rank] = out
+    for p in procs:
+        p.join(timeout=60)
+    (t_first, t_second), timed_out = res[0]
+    assert timed_out
+    assert 0.2 < t_first < 30.0, t_first          # ~3 s at ~0.4 us per poll; generous bounds, but not minutes
+    assert t_second < 0.5 * t_first and t_second < 1.0, (t_first, t_second)

@@ -17,8 +17,11 @@
 namespace vaek {
 
 constexpr int kMaxWorld = 8;
-constexpr unsigned kSpinLimit = 1u << 27;      // x (load + s_sleep 8, >= ~0.2 us): gives up after ~30 s -- ranks of a job
-                                               // can be seconds apart at start-up (graph capture, first launches)
+constexpr unsigned kSpinLimit = 1u << 23;      // x (uncached load + s_sleep 8, ~0.4 us measured): a lane gives up after ~3 s in total.
+                                               // Every exchange follows a host-side barrier or the previous exchange, so
+                                               // ranks are milliseconds apart; once any exchange on this rank has given up
+                                               // (status word), later ones do not wait at all -- a dead link costs seconds,
+                                               // not world x steps x the limit, before the host falls back to RCCL.
 
 struct CommDev {
     unsigned long long* peer[kMaxWorld];      // peer[r] = rank r's granule region (peer[rank] = local)
@@ -33,13 +36,15 @@ __device__ __forceinline__ float comm_exchange_sum(const CommDev& c, unsigned ep
         __hip_atomic_store(c.peer[p] + slot + (long long)c.rank * c.ng, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long* own = c.peer[c.rank] + slot;
     float sum = 0.f;
+    unsigned spins = 0;                       // shared by the polls of all ranks: the bound is per exchange
+    bool dead = false;
     for (int r = 0; r < c.world; ++r) {
         unsigned long long g = 0;
-        unsigned spins = 0;
         for (;;) {
             g = __hip_atomic_load(own + (long long)r * c.ng, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if ((unsigned)(g >> 32) == epoch) break;
-            if (++spins > kSpinLimit) { __hip_atomic_store(c.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if ((unsigned)(g >> 32) == epoch || dead) break;
+            if (spins == 0) dead = __hip_atomic_load(c.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (++spins > kSpinLimit) { __hip_atomic_store(c.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = true; }
             __builtin_amdgcn_s_sleep(8);
         }
         sum += __uint_as_float((unsigned)g);
