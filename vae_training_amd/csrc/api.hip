@@ -63,6 +63,9 @@ static int check_ws(const vaek_ctx* c, const void* ws) {
     return VAEK_OK;
 }
 
+// dW|db slabs are flat-gradient images at a 64-float-aligned pitch (16-byte loads in the streaming reductions)
+static inline int64_t slab_stride(const vaek_ctx* c) { return (int64_t)align_up((size_t)c->P, 64); }
+
 template <typename T>
 static T* at(void* ws, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(ws) + off); }
 
@@ -110,12 +113,12 @@ static int net_backward(vaek_ctx* c, const Net& net, const float* params, const 
         const float* w = params + l.w_off;
         const float* h_in = i == 0 ? in : at<float>(ws, net.act_off[i - 1]);
         const bool h16 = use_bf16(c, l.n_in, l.n_out);
-        int rc = (h16 ? launch_dense_bwd_dw_bf16 : launch_dense_bwd_dw)(h_in, d, slabs + l.w_off, c->P, l.S, l.rows_per_split,
+        int rc = (h16 ? launch_dense_bwd_dw_bf16 : launch_dense_bwd_dw)(h_in, d, slabs + l.w_off, slab_stride(c), l.S, l.rows_per_split,
                                                                         c->B, l.n_in, l.n_out, st);
         if (rc) return rc;
         if (sink) {     // this layer's [kernel | bias] slice is final once its slabs are summed: announce it
             const int64_t cnt = (int64_t)(l.n_in + 1) * l.n_out;
-            if ((rc = launch_sum_slabs(slabs + l.w_off, c->P, l.S, sink->grads + l.w_off, cnt, st))) return rc;
+            if ((rc = launch_sum_slabs(slabs + l.w_off, slab_stride(c), l.S, sink->grads + l.w_off, cnt, st))) return rc;
             VAEK_HIP_CHECK(hipEventRecord((hipEvent_t)sink->events[sink->next++], st));
         }
         if (i > 0) {
@@ -163,11 +166,13 @@ static int generic_grads(vaek_ctx* c, const float* params, int32_t* step_dev, co
     return net_backward(c, c->enc, params, x, dsamp, ws, nullptr, false, st, sink);
 }
 
+constexpr int64_t kBulkFinalizeMin = 65536;      // parameters below which the 64-output finalize alone is faster
+
 static int generic_finalize(vaek_ctx* c, const float* params, float* grads, float* params_rw, float* m, float* v,
                             const int32_t* step_dev, float lr, void* ws, hipStream_t st, int64_t lo = 0) {
     FinalizeArgs f{};
     f.lo = lo;
-    f.slabs = at<float>(ws, c->ws_slabs); f.slab_stride = c->P; f.S = c->S;
+    f.slabs = at<float>(ws, c->ws_slabs); f.slab_stride = slab_stride(c); f.S = c->S;
     f.nseg = 0;
     for (const Net* net : {&c->enc, &c->dec, &c->sig})
         for (const auto& l : net->layers) {
@@ -186,10 +191,16 @@ static int generic_finalize(vaek_ctx* c, const float* params, float* grads, floa
     f.loss_hist = c->cfg.world == 1 ? c->loss_hist : nullptr; f.loss_hist_cap = c->loss_hist_cap;
     if (!f.step_dev) f.loss_hist = nullptr;
     const bool fuse = params_rw != nullptr && c->L + 5 <= 64;
+    int rc;
+    int64_t adam_from = 0;
+    if (lo == 0 && c->off_epsp >= kBulkFinalizeMin) {
+        // big models: weights and biases as a streaming pass (with Adam), the 64-output finalize only for the tail
+        if ((rc = launch_bulk_finalize(f, c->off_epsp, st))) return rc;
+        f.lo = adam_from = c->off_epsp;
+    }
     if (!fuse) f.params_rw = nullptr;
-    int rc = launch_finalize(f, st);
-    if (rc || params_rw == nullptr || fuse) return rc;
-    return launch_adam(params_rw, grads, m, v, c->P, lr, 0, step_dev, 1.f, st);
+    if ((rc = launch_finalize(f, st)) || params_rw == nullptr || fuse) return rc;
+    return launch_adam(params_rw + adam_from, grads + adam_from, m + adam_from, v + adam_from, c->P - adam_from, lr, 0, step_dev, 1.f, st);
 }
 
 }  // namespace vaek
@@ -259,8 +270,10 @@ int vaek_ctx_create(const vaek_config* cfg, vaek_ctx** out) {
     c->S = 1; c->rows_per_split = c->B;
     auto splits = [&](Net& n) {
         for (auto& l : n.layers) {
-            const int tiles = ((l.n_in + 1 + 63) / 64) * ((l.n_out + 63) / 64);
-            const int s_target = std::min(256, std::max(4, 1024 / tiles));
+            // wide layers run 128 x 128 tiles (gemm_f32.hip) and want ~3 workgroups per CU; the rest 64-wide tiles
+            const bool wide = l.n_in + 1 >= 128 && l.n_out >= 128;
+            const int tiles = wide ? ((l.n_in + 1 + 127) / 128) * ((l.n_out + 127) / 128) : ((l.n_in + 1 + 63) / 64) * ((l.n_out + 63) / 64);
+            const int s_target = std::min(256, std::max(4, (wide ? 768 : 1024) / tiles));
             l.rows_per_split = std::max(64, (int)align_up((size_t)(c->B + s_target - 1) / s_target, 64));
             l.S = (c->B + l.rows_per_split - 1) / l.rows_per_split;
             if (l.S > c->S) { c->S = l.S; c->rows_per_split = l.rows_per_split; }
@@ -281,7 +294,7 @@ int vaek_ctx_create(const vaek_config* cfg, vaek_ctx** out) {
     c->ws_dsamp = off; off = align_up(off + (size_t)c->B * c->L * sizeof(float), 256);
     c->ws_gbuf0 = off; off = align_up(off + (size_t)c->B * c->max_width * sizeof(float), 256);
     c->ws_gbuf1 = off; off = align_up(off + (size_t)c->B * c->max_width * sizeof(float), 256);
-    c->ws_slabs = off; off = align_up(off + (size_t)c->S * c->P * sizeof(float), 256);
+    c->ws_slabs = off; off = align_up(off + (size_t)c->S * slab_stride(c) * sizeof(float), 256);
     c->ws_epart = off; off = align_up(off + (size_t)c->Se * 4 * sizeof(float), 256);
     c->ws_rpart = off; off = align_up(off + (size_t)c->Se * c->L * sizeof(float), 256);
     c->fused = !cfg->force_generic && fused_supported(c);

@@ -164,6 +164,19 @@ __device__ __forceinline__ void adam_bias_corrections(int t, float& bc1, float& 
 // always sit in block 0.  1024 threads = 64 outputs x 16 row groups: every thread walks its share of
 // the S dW|db slabs / Se elementwise partial rows with independent loads, then a fixed-order sum.
 constexpr int FINQ = 16;
+// sum of p[s * stride] over s = q, q + FINQ, ... < n, in that order -- but with 8 loads in flight: a model with 1024
+// elementwise splits made this a chain of 64 dependent ~1 us loads in the one workgroup that owns the loss (60 us)
+__device__ __forceinline__ float strided_sum(const float* p, long long stride, int q, int n) {
+    float acc = 0.f;
+    for (int s0 = q; s0 < n; s0 += FINQ * 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int s = s0 + u * FINQ; t[u] = s < n ? p[(long long)s * stride] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += t[u];
+    }
+    return acc;
+}
 __global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeArgs a) {
     __shared__ float part[FINQ][64];
     __shared__ float sums[64];
@@ -179,18 +192,16 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeArgs a) {
     float acc = 0.f;
     if (i >= 0 && i < a.P) {
         if (i == a.off_eps) {
-            for (int s = q; s < a.Se; s += FINQ) acc += a.epart[s * 4 + 2];
+            acc = strided_sum(a.epart + 2, 4, q, a.Se);
         } else if (i >= a.off_epsp && i < a.off_epsp + a.L) {
-            const float* r = a.rpart + (i - a.off_epsp);
-            for (int s = q; s < a.Se; s += FINQ) acc += r[(long long)s * a.L];
+            acc = strided_sum(a.rpart + (i - a.off_epsp), a.L, q, a.Se);
         } else {
             int S = a.S;                               // slabs written for this output's layer
             for (int k = a.nseg - 1; k >= 0; --k) if (i < a.seg_end[k]) S = a.seg_S[k];
-            const float* p = a.slabs + i;
-            for (int s = q; s < S; s += FINQ) acc += p[(long long)s * a.slab_stride];
+            acc = strided_sum(a.slabs + i, a.slab_stride, q, S);
         }
     } else if (i == a.P || i == a.P + 1) {
-        for (int s = q; s < a.Se; s += FINQ) acc += a.epart[s * 4 + (int)(i - a.P)];      // sum mse terms, sum mu^2
+        acc = strided_sum(a.epart + (int)(i - a.P), 4, q, a.Se);                           // sum mse terms, sum mu^2
     }
     part[q][o] = acc;
     float kl = 0.f;                                   // closed-form KL constant sum_l (1 + lv - e^lv), block 0 only
@@ -246,7 +257,67 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const FinalizeArgs a) {
 int launch_finalize(const FinalizeArgs& a, hipStream_t st) {
     const long long n = a.P + kExtra;
     ProfScope ps(a.params_rw ? "finalize_adam" : "finalize", st);
-    launch_k(ps, finalize_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, st, a);
+    // block b covers outputs [n - 64(b+1), n - 64b): with a floor `lo` only the blocks reaching above it are launched
+    const long long nblk = (n - std::max(0ll, a.lo) + 63) / 64;
+    launch_k(ps, finalize_kernel, dim3((unsigned)nblk), dim3(1024), 0, st, a);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+// Large models (C3: 1.06 M parameters, 14 slabs): the weights and biases [0, hi) are a plain streaming reduction --
+// 16-byte loads, slab after slab in ascending order (the order finalize_kernel and sum_slabs_kernel use), Adam in the
+// same pass -- and finalize_kernel keeps only the tail it exists for (epsilon_p, epsilon, the loss sums), which
+// 64-output workgroups reading 256-byte runs of each slab did at 0.6 TB/s.
+__global__ __launch_bounds__(256) void bulk_finalize_kernel(const FinalizeArgs a, const long long hi) {
+    const long long i0 = 4 * ((long long)blockIdx.x * blockDim.x + threadIdx.x);
+    if (i0 >= hi) return;
+    auto slabs_of = [&](long long i) { int S = a.S;
+        for (int k = a.nseg - 1; k >= 0; --k) if (i < a.seg_end[k]) S = a.seg_S[k];
+        return S; };
+    float bc1 = 1.f, bc2 = 1.f;
+    if (a.params_rw) adam_bias_corrections(a.step_dev[0], bc1, bc2);
+    const int S0 = slabs_of(i0);
+    const bool vec = i0 + 3 < hi && slabs_of(i0 + 3) == S0 && a.slab_stride % 4 == 0 &&
+                     (((uintptr_t)a.slabs | (uintptr_t)a.grads | (uintptr_t)a.params_rw | (uintptr_t)a.m | (uintptr_t)a.v) & 15) == 0;
+    if (vec) {
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s0 = 0; s0 < S0; s0 += 8) {           // 8 independent 16-byte loads in flight, summed in slab order
+            float4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                t[u] = s0 + u < S0 ? *reinterpret_cast<const float4*>(a.slabs + (long long)(s0 + u) * a.slab_stride + i0)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { g.x += t[u].x; g.y += t[u].y; g.z += t[u].z; g.w += t[u].w; }
+        }
+        *reinterpret_cast<float4*>(a.grads + i0) = g;
+        if (a.params_rw) {
+            float4 p = *reinterpret_cast<const float4*>(a.params_rw + i0), m = *reinterpret_cast<const float4*>(a.m + i0),
+                   v = *reinterpret_cast<const float4*>(a.v + i0);
+            adam_apply(p.x, g.x, m.x, v.x, a.lr, bc1, bc2); adam_apply(p.y, g.y, m.y, v.y, a.lr, bc1, bc2);
+            adam_apply(p.z, g.z, m.z, v.z, a.lr, bc1, bc2); adam_apply(p.w, g.w, m.w, v.w, a.lr, bc1, bc2);
+            *reinterpret_cast<float4*>(a.params_rw + i0) = p; *reinterpret_cast<float4*>(a.m + i0) = m;
+            *reinterpret_cast<float4*>(a.v + i0) = v;
+        }
+        return;
+    }
+    for (long long i = i0; i < std::min(hi, i0 + 4); ++i) {
+        const int S = slabs_of(i);
+        float g = 0.f;
+        for (int s = 0; s < S; ++s) g += a.slabs[(long long)s * a.slab_stride + i];
+        a.grads[i] = g;
+        if (a.params_rw) {
+            float p = a.params_rw[i], m = a.m[i], v = a.v[i];
+            adam_apply(p, g, m, v, a.lr, bc1, bc2);
+            a.params_rw[i] = p; a.m[i] = m; a.v[i] = v;
+        }
+    }
+}
+
+int launch_bulk_finalize(const FinalizeArgs& a, int64_t hi, hipStream_t st) {
+    if (hi <= 0) return VAEK_OK;
+    ProfScope ps(a.params_rw ? "bulk_finalize_adam" : "bulk_finalize", st);
+    launch_k(ps, bulk_finalize_kernel, dim3((unsigned)((hi + 1023) / 1024)), dim3(256), 0, st, a, (long long)hi);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
 }

@@ -7,7 +7,7 @@
 //   forward   Y[B,N]   = act(X[B,K] W[K,N] + b)            A: k-contiguous, B: n-contiguous
 //   dX        dX[B,K]  = (dY[B,N] W^T) * relu'(X)          A: k-contiguous, B: k-contiguous
 //   dW | db   G[K+1,N] = [X | 1]^T dY   split over batch   A: m-contiguous (+ones row), B: n-contiguous
-// Block = 256 threads = 4 waves, each wave one 32x32 MFMA tile; output tile 64x64, 128x32 or 32x128; BK = 16.
+// Block = 256 threads = 4 waves, each wave TM x TN 32x32 MFMA tiles; output tile 64x64, 128x128, 128x32 or 32x128.
 // LDS tiles are k-major ([k][m] / [k][n]) so every MFMA operand read is 32 consecutive floats
 // (conflict-free ds_read_b32); the next K-tile is fetched into registers while the MFMAs of the
 // current one run (issue-early / write-late staging).
@@ -111,9 +111,9 @@ __device__ __forceinline__ void store_mncont(float* s, const float (&v)[(T * BK 
     }
 }
 
-template <bool A_KCONT, bool B_KCONT, int EPI, int WM, int WN, int BK>
+template <bool A_KCONT, bool B_KCONT, int EPI, int WM, int WN, int BK, int TM = 1, int TN = 1>
 __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
-    constexpr int BM = 32 * WM, BN = 32 * WN, SA = BM + 4, SB = BN + 4;
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, SA = BM + 4, SB = BN + 4;
     __shared__ __attribute__((aligned(16))) float As[BK * SA];
     __shared__ __attribute__((aligned(16))) float Bs[BK * SB];
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s), so give each XCD
@@ -141,9 +141,13 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
                        (B_KCONT ? (kbeg % 4 == 0) : true);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    f32x16 acc;
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
 
     float ra[(BM * BK / 4 + NT - 1) / NT][4], rb[(BN * BK / 4 + NT - 1) / NT][4];
     auto fetch = [&](int k0) {
@@ -159,55 +163,70 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
         if (B_KCONT) store_kcont<BN, BK>(Bs, rb); else store_mncont<BN, BK>(Bs, rb);
         __syncthreads();
         if (k0 + BK < kend) fetch(k0 + BK);    // in flight under the MFMAs below
-        const float* pa = As + (lane >> 5) * SA + wm * 32 + (lane & 31);
-        const float* pb = Bs + (lane >> 5) * SB + wn * 32 + (lane & 31);
+        const float* pa = As + (lane >> 5) * SA + wm * 32 * TM + (lane & 31);
+        const float* pb = Bs + (lane >> 5) * SB + wn * 32 * TN + (lane & 31);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk * SA], pb[kk * SB], acc, 0, 0, 0);
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = pa[kk * SA + 32 * i];
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) bv[jn] = pb[kk * SB + 32 * jn];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[jn], acc[i][jn], 0, 0, 0);
         }
     }
-    // C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int col = n0 + wn * 32 + (lane & 31);
-    if (col >= g.N) return;
-    float bias = 0.f, sdev = 0.f;
-    if (EPI == EPI_FWD || EPI == EPI_REPARAM) bias = g.bias ? g.bias[col] : 0.f;
-    if (EPI == EPI_REPARAM) sdev = expf(0.5f * g.lv[col]);
-    float* C = g.C;
-    if (EPI == EPI_DW) C += (long long)bz * g.slab_stride;
+    // C/D map of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= g.M) continue;
-        const long long o = (long long)row * g.ldc + col;
-        float v = acc[r];
-        if (EPI == EPI_FWD) {
-            v += bias;
-            if (g.relu) v = fmaxf(v, 0.f);
-            C[o] = v;
-        } else if (EPI == EPI_REPARAM) {
-            v += bias;
-            C[o] = v;
-            g.C2[o] = v + sdev * g.aux[o];
-        } else if (EPI == EPI_DX) {
-            if (g.relu) v = g.aux[o] > 0.f ? v : 0.f;
-            if (g.accumulate) v += C[o];
-            C[o] = v;
-        } else {
-            C[o] = v;
+    for (int jn = 0; jn < TN; ++jn) {
+        const int col = n0 + (wn * TN + jn) * 32 + (lane & 31);
+        if (col >= g.N) continue;
+        float bias = 0.f, sdev = 0.f;
+        if (EPI == EPI_FWD || EPI == EPI_REPARAM) bias = g.bias ? g.bias[col] : 0.f;
+        if (EPI == EPI_REPARAM) sdev = expf(0.5f * g.lv[col]);
+        float* C = g.C;
+        if (EPI == EPI_DW) C += (long long)bz * g.slab_stride;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= g.M) continue;
+                const long long o = (long long)row * g.ldc + col;
+                float v = acc[i][jn][r];
+                if (EPI == EPI_FWD) {
+                    v += bias;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    C[o] = v;
+                } else if (EPI == EPI_REPARAM) {
+                    v += bias;
+                    C[o] = v;
+                    g.C2[o] = v + sdev * g.aux[o];
+                } else if (EPI == EPI_DX) {
+                    if (g.relu) v = g.aux[o] > 0.f ? v : 0.f;
+                    if (g.accumulate) v += C[o];
+                    C[o] = v;
+                } else {
+                    C[o] = v;
+                }
+            }
         }
     }
 }
 
-template <bool A_KCONT, bool B_KCONT, int EPI, int WM, int WN, int BK>
+template <bool A_KCONT, bool B_KCONT, int EPI, int WM, int WN, int BK, int TM = 1, int TN = 1>
 static int launch_shape(const GemmArgs& g, int splits, hipStream_t st) {
     ProfScope ps(EPI == EPI_FWD ? "gemm_f32_fwd" : EPI == EPI_REPARAM ? "gemm_f32_fwd_reparam"
                  : EPI == EPI_DX ? "gemm_f32_dx" : "gemm_f32_dw", st);
-    dim3 grid((g.N + 32 * WN - 1) / (32 * WN), (g.M + 32 * WM - 1) / (32 * WM), splits);
+    dim3 grid((g.N + 32 * WN * TN - 1) / (32 * WN * TN), (g.M + 32 * WM * TM - 1) / (32 * WM * TM), splits);
     if (grid.y > 65535u || grid.z > 65535u) {
         set_error("gemm grid too large (M=%d N=%d splits=%d)", g.M, g.N, splits);
         return VAEK_ERR_INVALID;
     }
-    launch_k(ps, (gemm_f32_kernel<A_KCONT, B_KCONT, EPI, WM, WN, BK>), grid, dim3(NT), 0, st, g);
+    launch_k(ps, (gemm_f32_kernel<A_KCONT, B_KCONT, EPI, WM, WN, BK, TM, TN>), grid, dim3(NT), 0, st, g);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
 }
@@ -218,6 +237,17 @@ static int launch(const GemmArgs& g, int splits, hipStream_t st) {
     // skinny shapes stream a long K past a small output: a 32-deep k-tile halves their barriers per byte
     if (g.N <= 32) return launch_shape<A_KCONT, B_KCONT, EPI, 4, 1, 32>(g, splits, st);     // skinny output: 128 x 32
     if (g.M <= 32) return launch_shape<A_KCONT, B_KCONT, EPI, 1, 4, 32>(g, splits, st);     // skinny M:      32 x 128
+    // wide layers: 128 x 128 (each wave 2 x 2 MFMA tiles) halves the operand bytes pulled through L2 per flop -- at
+    // 64 x 64 the 512-wide layers of C3 need ~7 TB/s of L2 -> LDS traffic to keep the f32 matrix pipe busy (C3 forward
+    // 1.75 -> 1.53 ms, dX 2.22 -> 1.93 ms, dW|db 2.23 -> 2.02 ms with the split count raised to match, api.hip).  Only
+    // where the big tiles still give every CU two workgroups (C2, 8 192 rows: 128 tiles, is faster at 64 x 64) and
+    // the reduction is long enough to matter (C4's 20 -> 4096 decoder is all epilogue: 148 us at 64 x 64, 186 at 128).
+    // Measured and dropped here: BK = 32 (3 waves per SIMD instead of 4: 5-8 % slower), a split count that makes the
+    // workgroups a whole number per CU (2 per CU: 15 % slower than 2.4), the ones row of [X | 1]^T as a streaming
+    // column sum instead of a fifth MFMA tile row (no change: the kernel is latency-, not MFMA-bound), dX on a
+    // pre-transposed copy of W so that its B operand stages with 16-byte LDS stores like the forward's (no change).
+    if (g.M >= 128 && g.N >= 128 && g.K >= 128 && (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * splits >= 512)
+        return launch_shape<A_KCONT, B_KCONT, EPI, 2, 2, 16, 2, 2>(g, splits, st);
     return launch_shape<A_KCONT, B_KCONT, EPI, 2, 2, 16>(g, splits, st);                    // 64 x 64
 }
 

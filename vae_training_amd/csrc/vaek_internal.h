@@ -158,6 +158,8 @@ struct FinalizeArgs {
     long long lo;             // outputs below lo are left alone (bucketed mode finalises the tail only)
 };
 int launch_finalize(const FinalizeArgs& a, hipStream_t st);
+// streaming slab sum (+ Adam) of the outputs [0, hi); pair with launch_finalize(lo = hi) for the tail
+int launch_bulk_finalize(const FinalizeArgs& a, int64_t hi, hipStream_t st);
 int launch_adam(float* params, const float* grads, float* m, float* v, int64_t n, float lr, int step,
                 const int32_t* step_dev, float grad_scale, hipStream_t st);
 // x_hat = y_lin (+ sigmoid(y_sig)) + z2 * exp(eps/2)
