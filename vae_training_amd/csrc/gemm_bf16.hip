@@ -7,8 +7,8 @@
 // float64 oracle: tests/test_gpu_bf16.py; the 1e-5 ELBO contract stays with the f32 path).
 //
 // Block = 256 threads = 4 waves (2x2), 128x128 output tile, each wave 64x64 = 2x2 MFMA tiles of 32x32,
-// BK = 32 (two 16-deep MFMA steps).  LDS tiles are [row][k] with k contiguous and an 80-byte row stride
-// (32 bf16 + 8 pad): the 16-byte fragment reads (lane = row, 8 consecutive k) are conflict-free, and an
+// BK = 32 or 64 (16-deep MFMA steps).  LDS tiles are [row][k] with k contiguous and an 80- or 144-byte row stride
+// (BK bf16 + 8 pad): the 16-byte fragment reads (lane = row, 8 consecutive k) are conflict-free, and an
 // operand whose k runs contiguously in memory is staged with 8-byte writes.  The next K-tile is fetched
 // into registers while the MFMAs of the current one run.
 #include "vaek_internal.h"
@@ -19,7 +19,12 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 
-constexpr int HBM_ = 128, HBN_ = 128, HBK = 32, HSTR = 40, HNT = 256;     // HSTR in bf16 elements (80 bytes)
+constexpr int HBM_ = 128, HBN_ = 128, HNT = 256;
+// The k-tile depth HBK is a template parameter; every use runs 32.  64 was measured: the batch-split dW|db looked
+// faster in isolation (909 -> 678 us under per-kernel timestamps) but the C3 step replayed from a hipGraph went from
+// 2.73 to 2.94 ms with it, and dX got 14 % slower even in isolation -- at K = layer width a workgroup has 8-16 k-tiles
+// and occupancy (VGPRs) matters more than barriers.  LDS rows are HBK + 8 bf16 (80 bytes at 32; 144 at 64: both
+// conflict-free for the 16-byte fragment reads); HKU = float4 units per thread and operand tile.
 
 enum { HEPI_FWD = 0, HEPI_REPARAM = 1, HEPI_DX = 2, HEPI_DW = 3 };
 
@@ -34,14 +39,16 @@ struct HGemmArgs {
     int k_per_split; long long slab_stride;
 };
 
-// tile = 128 (mn) x 32 (k).  k-contiguous source p[mn*ld + k]: thread -> rows (t>>3) + 32u, 4 consecutive k.
+// tile = 128 (mn) x HBK (k).  k-contiguous source p[mn*ld + k]: thread -> rows (t / (HBK/4)) + (1024/HBK) u, 4 consecutive k.
+template <int HBK, int HKU = HBK / 8>
 __device__ __forceinline__ void hfetch_kcont(const float* __restrict__ p, int ld, int mn0, int MN, int k0, int kend,
-                                             bool vec_ok, float (&v)[4][4]) {
+                                             bool vec_ok, float (&v)[HKU][4]) {
+    constexpr int TPR = HBK / 4, RPP = HNT / TPR;       // threads per row, rows per pass
     const int t = threadIdx.x;
-    const int k = k0 + (t & 7) * 4;
+    const int k = k0 + (t % TPR) * 4;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int mn = mn0 + (t >> 3) + 32 * u;
+    for (int u = 0; u < HKU; ++u) {
+        const int mn = mn0 + t / TPR + RPP * u;
         v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0.f;
         if (mn < MN) {
             const float* q = p + (long long)mn * ld + k;
@@ -55,26 +62,29 @@ __device__ __forceinline__ void hfetch_kcont(const float* __restrict__ p, int ld
         }
     }
 }
-__device__ __forceinline__ void hstore_kcont(__bf16* s, const float (&v)[4][4]) {
+template <int HBK, int HKU = HBK / 8, int HSTR = HBK + 8>
+__device__ __forceinline__ void hstore_kcont(__bf16* s, const float (&v)[HKU][4]) {
+    constexpr int TPR = HBK / 4, RPP = HNT / TPR;
     const int t = threadIdx.x;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < HKU; ++u) {
         bf16x4 h = {(__bf16)v[u][0], (__bf16)v[u][1], (__bf16)v[u][2], (__bf16)v[u][3]};
-        *reinterpret_cast<bf16x4*>(&s[((t >> 3) + 32 * u) * HSTR + (t & 7) * 4]) = h;
+        *reinterpret_cast<bf16x4*>(&s[(t / TPR + RPP * u) * HSTR + (t % TPR) * 4]) = h;
     }
 }
 // mn-contiguous source p[k*ld + mn] (the operand must be TRANSPOSED into the [row][k] image): thread ->
-// ONE row mn = t & 127 and 16 consecutive k = 16 (t >> 7) ..: the 16 dword loads are coalesced along mn
-// (256 B per wave and k), and the thread then owns 32 contiguous bytes of its LDS row -> two 16-byte
-// writes at the conflict-free 80-byte row stride (a 2-byte scatter would be a 16-way bank conflict).
+// ONE row mn = t & 127 and HBK/2 consecutive k = (HBK/2)(t >> 7) ..: the dword loads are coalesced along mn
+// (256 B per wave and k), and the thread then owns HBK contiguous bytes of its LDS row -> 16-byte
+// writes at the conflict-free row stride (a 2-byte scatter would be a 16-way bank conflict).
+template <int HBK, int HKU = HBK / 8>
 __device__ __forceinline__ void hfetch_mncont(const float* __restrict__ p, int ld, int mn0, int mem, bool aug, int k0,
-                                              int kend, bool /*vec_ok*/, float (&v)[4][4]) {
+                                              int kend, bool /*vec_ok*/, float (&v)[HKU][4]) {
     const int t = threadIdx.x;
     const int mn = mn0 + (t & 127);
-    const int kb = k0 + 16 * (t >> 7);
+    const int kb = k0 + (HBK / 2) * (t >> 7);
     const float* q = p + (long long)kb * ld + mn;
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < HKU; ++u)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int k = kb + 4 * u + c;
@@ -86,19 +96,21 @@ __device__ __forceinline__ void hfetch_mncont(const float* __restrict__ p, int l
             v[u][c] = x;
         }
 }
-__device__ __forceinline__ void hstore_mncont(__bf16* s, const float (&v)[4][4]) {
+template <int HBK, int HKU = HBK / 8, int HSTR = HBK + 8>
+__device__ __forceinline__ void hstore_mncont(__bf16* s, const float (&v)[HKU][4]) {
     const int t = threadIdx.x;
-    __bf16* row = s + (t & 127) * HSTR + 16 * (t >> 7);
+    __bf16* row = s + (t & 127) * HSTR + (HBK / 2) * (t >> 7);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < HKU / 2; ++h) {
         bf16x8 w = {(__bf16)v[2 * h][0], (__bf16)v[2 * h][1], (__bf16)v[2 * h][2], (__bf16)v[2 * h][3],
                     (__bf16)v[2 * h + 1][0], (__bf16)v[2 * h + 1][1], (__bf16)v[2 * h + 1][2], (__bf16)v[2 * h + 1][3]};
         *reinterpret_cast<bf16x8*>(row + 8 * h) = w;
     }
 }
 
-template <bool A_KCONT, bool B_KCONT, int EPI>
+template <bool A_KCONT, bool B_KCONT, int EPI, int HBK>
 __global__ __launch_bounds__(HNT) void gemm_bf16_kernel(const HGemmArgs g) {
+    constexpr int HSTR = HBK + 8, HKU = HBK / 8;
     __shared__ __attribute__((aligned(16))) __bf16 As[HBM_ * HSTR];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[HBN_ * HSTR];
     // XCD-aware tile order (see gemm_f32.hip): each XCD walks a contiguous run of the x-fastest tile space
@@ -129,25 +141,25 @@ __global__ __launch_bounds__(HNT) void gemm_bf16_kernel(const HGemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float ra[4][4], rb[4][4];
+    float ra[HKU][4], rb[HKU][4];
     auto fetch = [&](int k0) {
-        if (A_KCONT) hfetch_kcont(g.A, g.lda, m0, g.M, k0, kend, a_vec, ra);
-        else hfetch_mncont(g.A, g.lda, m0, g.a_mem, EPI == HEPI_DW, k0, kend, a_vec, ra);
-        if (B_KCONT) hfetch_kcont(g.B, g.ldb, n0, g.N, k0, kend, b_vec, rb);
-        else hfetch_mncont(g.B, g.ldb, n0, g.N, false, k0, kend, b_vec, rb);
+        if (A_KCONT) hfetch_kcont<HBK>(g.A, g.lda, m0, g.M, k0, kend, a_vec, ra);
+        else hfetch_mncont<HBK>(g.A, g.lda, m0, g.a_mem, EPI == HEPI_DW, k0, kend, a_vec, ra);
+        if (B_KCONT) hfetch_kcont<HBK>(g.B, g.ldb, n0, g.N, k0, kend, b_vec, rb);
+        else hfetch_mncont<HBK>(g.B, g.ldb, n0, g.N, false, k0, kend, b_vec, rb);
     };
     if (kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += HBK) {
         __syncthreads();
-        if (A_KCONT) hstore_kcont(As, ra); else hstore_mncont(As, ra);
-        if (B_KCONT) hstore_kcont(Bs, rb); else hstore_mncont(Bs, rb);
+        if (A_KCONT) hstore_kcont<HBK>(As, ra); else hstore_mncont<HBK>(As, ra);
+        if (B_KCONT) hstore_kcont<HBK>(Bs, rb); else hstore_mncont<HBK>(Bs, rb);
         __syncthreads();
         if (k0 + HBK < kend) fetch(k0 + HBK);
         // fragments: lane (row = lane&31, half = lane>>5) holds k = 16s + 8*half .. +7 of its row
         const __bf16* pa = As + (wm * 64 + (lane & 31)) * HSTR + 8 * (lane >> 5);
         const __bf16* pb = Bs + (wn * 64 + (lane & 31)) * HSTR + 8 * (lane >> 5);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < HBK / 16; ++s) {
             bf16x8 fa[2], fb[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(pa + i * 32 * HSTR + 16 * s);
@@ -202,7 +214,7 @@ static int hlaunch(const HGemmArgs& g, int splits, hipStream_t st) {
                  : EPI == HEPI_DX ? "gemm_bf16_dx" : "gemm_bf16_dw", st);
     dim3 grid((g.N + HBN_ - 1) / HBN_, (g.M + HBM_ - 1) / HBM_, splits);
     if (grid.y > 65535u || grid.z > 65535u) { set_error("gemm grid too large (M=%d N=%d splits=%d)", g.M, g.N, splits); return VAEK_ERR_INVALID; }
-    launch_k(ps, (gemm_bf16_kernel<A_KCONT, B_KCONT, EPI>), grid, dim3(HNT), 0, st, g);
+    launch_k(ps, (gemm_bf16_kernel<A_KCONT, B_KCONT, EPI, 32>), grid, dim3(HNT), 0, st, g);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
 }
