@@ -226,6 +226,11 @@ int vaek_microbench_copy(vaek_ctx* ctx, const void* src, void* dst, int64_t byte
 int vaek_microbench_mfma(vaek_ctx* ctx, int32_t kind, int32_t iters, int32_t waves_per_simd, float* scratch,
                          double* flops_out, void* stream);
 
+/* Launch floor of this platform: n back-to-back launches of a kernel of `blocks` workgroups that does nothing (kind 0)
+ * or one dependent pair of loads per thread (kind 1; p = >= 65 small ints, out = >= blocks ints).  Time them with
+ * vaek_profile_* (kernel timestamps) or around a hipGraph replay (launch-to-launch interval). */
+int vaek_microbench_launch(vaek_ctx* ctx, int32_t kind, int32_t blocks, int32_t n, const int32_t* p, int32_t* out, void* stream);
+
 /* ---- in-process kernel timing (bench.py's roofline leg) --------------------------------------- */
 /* Between begin and report every kernel the library launches for this context is bracketed by a
  * pair of hipEvents recorded on the launch stream (pool of max_records pairs, allocated here, so

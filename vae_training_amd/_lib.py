@@ -70,6 +70,7 @@ SIGNATURES = {
     "vaek_rng_fill": (C.c_int, [_vp, _vp, _vp, _i64, C.c_uint64, C.c_uint32, C.c_uint32, _vp]),
     "vaek_set_loss_history": (C.c_int, [_vp, _vp, _i64]),
     "vaek_microbench_copy": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "vaek_microbench_launch": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "vaek_microbench_mfma": (C.c_int, [_vp, _i32, _i32, _i32, _vp, C.POINTER(C.c_double), _vp]),
     "vaek_profile_begin": (C.c_int, [_vp, _i32]),
     "vaek_profile_report": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),

@@ -51,7 +51,30 @@ __global__ __launch_bounds__(256) void mfma_loop_kernel(float* out, int iters) {
 
 using namespace vaek;
 
+namespace vaek {
+// launch floor probes: kind 0 = nothing at all; 1 = every thread of `blocks` workgroups does ONE dependent pair of
+// loads (pointer chase through p[0]) and a store -- the shape of fused_finalize_kernel's critical path
+__global__ __launch_bounds__(256) void launch_probe_kernel(int kind, const int* p, int* out) {
+    if (kind == 0) return;
+    const int i = p[0];
+    const int v = p[1 + ((i + threadIdx.x) & 63)];
+    if (v == 0x7fffffff) out[blockIdx.x] = v;      // never true: p holds small numbers
+}
+}  // namespace vaek
+
 extern "C" {
+
+int vaek_microbench_launch(vaek_ctx* ctx, int32_t kind, int32_t blocks, int32_t n, const int32_t* p, int32_t* out, void* stream) {
+    if (!ctx || kind < 0 || kind > 1 || blocks <= 0 || n <= 0 || (kind == 1 && (!p || !out))) { set_error("vaek_microbench_launch: invalid argument"); return VAEK_ERR_INVALID; }
+    g_prof = &ctx->prof;
+    for (int i = 0; i < n; ++i) {
+        ProfScope ps(kind == 0 ? "microbench_launch_empty" : "microbench_launch_load", (hipStream_t)stream);
+        launch_k(ps, launch_probe_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (int)kind, (const int*)p, (int*)out);
+    }
+    g_prof = nullptr;
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
 
 int vaek_microbench_copy(vaek_ctx* ctx, const void* src, void* dst, int64_t bytes, void* stream) {
     if (!ctx || !src || !dst || bytes <= 0 || bytes % 16) { set_error("vaek_microbench_copy: invalid argument"); return VAEK_ERR_INVALID; }
