@@ -344,6 +344,7 @@ def main():
                         "param_bytes_per_step": 32 * P}
             if rank == 0:       # the same denominators re-measured on THIS box by the library's micro-benchmarks
                 roofline["peak_measured"] = eng.measure_peaks()
+                roofline["peak_measured"]["empty_kernel_launch_interval_us_in_hipGraph"] = eng.measure_launch_floor()
 
     # ---- auxiliary (never `value`): the same step with FRESH inputs drawn on the device every step, as the
     # reference's loop does (dataset.get_batch + sample_latent, model.py:221 / vae.py:125-128): the Philox draw of

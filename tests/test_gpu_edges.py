@@ -83,3 +83,20 @@ def test_error_codes_not_aborts():
     eng2 = Engine(64, 12, 20, world=2, rank=1, global_batch=128)
     with pytest.raises(_lib.VaekError, match="communicator"):
         eng2.train_step(f[:eng.P].clone(), f, f[:eng.P].clone(), f[:eng.P].clone(), step, x, z1, x, 1e-3)
+
+
+def test_launch_floor_probe():
+    """vaek_microbench_launch: the empty kernel and the one-dependent-load kernel run; the graph interval is microseconds."""
+    import ctypes as C
+    from vae_training_amd import _lib
+    from vae_training_amd.engine import Engine
+    eng = Engine(64, 12, 20)
+    p = torch.zeros(128, dtype=torch.int32, device="cuda")
+    out = torch.zeros(16, dtype=torch.int32, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(eng.lib.vaek_microbench_launch(eng.h, 1, 9, 3, C.c_void_p(p.data_ptr()), C.c_void_p(out.data_ptr()), st))
+    torch.cuda.synchronize()
+    assert int(out.abs().sum()) == 0
+    assert eng.lib.vaek_microbench_launch(eng.h, 1, 9, 3, None, None, st) != 0          # kind 1 needs its buffers
+    us = eng.measure_launch_floor(n=50, reps=5)
+    assert 0.2 < us < 50.0, us

@@ -234,6 +234,28 @@ class Engine:
             out[name.replace("microbench_", "") + "_TFLOPs"] = fl[name] * rep[name]["count"] / (rep[name]["total_ms"] * 1e-3) / 1e12
         return out
 
+    def measure_launch_floor(self, n=100, reps=20):
+        """Launch-to-launch interval (us) of a kernel that does nothing, replayed from a hipGraph chain of n launches:
+        what any two-kernel step pays before it computes anything."""
+        import time
+        launch = lambda k: _lib.check(self.lib.vaek_microbench_launch(self.h, 0, 1, k, None, None, _stream()))
+        launch(4)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                launch(n)
+        torch.cuda.current_stream().wait_stream(side)
+        g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g.replay()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / (n * reps) * 1e6
+
     # ---- building blocks -----------------------------------------------------------------------
     def dense_fwd(self, x, w, b, relu=False):
         rows, n_in = x.shape
