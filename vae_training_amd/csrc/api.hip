@@ -75,8 +75,12 @@ static T* at(void* ws, size_t off) { return reinterpret_cast<T*>(static_cast<cha
 static bool use_bf16(const vaek_ctx* c, int n_in, int n_out) { return c->cfg.dtype == VAEK_BF16 && n_in >= 64 && n_out >= 64; }
 
 // ---- forward through one Dense/relu stack; `reparam` fuses networks.py:73-74 into the last layer
+struct ElboFuse {           // decoder's last layer with the ELBO epilogue (gemm_f32.hip EPI_ELBO): inputs, and the tile map out
+    const float* x; const float* z2; const float* eps_param; float eps_cli, inv_bt; float* part; int bm, nbx;
+};
+
 static int net_forward(vaek_ctx* c, const Net& net, const float* params, const float* in, void* ws, int rows,
-                       bool reparam, const float* z1, hipStream_t st) {
+                       bool reparam, const float* z1, hipStream_t st, ElboFuse* ef = nullptr) {
     const float* h = in;
     for (size_t i = 0; i < net.layers.size(); ++i) {
         const Layer& l = net.layers[i];
@@ -85,7 +89,10 @@ static int net_forward(vaek_ctx* c, const Net& net, const float* params, const f
         float* y = at<float>(ws, net.act_off[i]);
         int rc;
         const bool h16 = use_bf16(c, l.n_in, l.n_out);
-        if (reparam && i + 1 == net.layers.size())
+        if (ef && i + 1 == net.layers.size())
+            rc = launch_dense_fwd_elbo(h, w, b, y, ef->x, ef->z2, ef->eps_param, ef->eps_cli, ef->inv_bt, ef->part, rows, l.n_in,
+                                       l.n_out, &ef->bm, &ef->nbx, st);
+        else if (reparam && i + 1 == net.layers.size())
             rc = (h16 ? launch_dense_fwd_reparam_bf16 : launch_dense_fwd_reparam)(h, w, b, y, at<float>(ws, c->ws_samples), z1,
                                                                                   params + c->off_epsp, rows, l.n_in, l.n_out, st);
         else
@@ -144,13 +151,29 @@ static int generic_grads(vaek_ctx* c, const float* params, int32_t* step_dev, co
     if ((rc = net_forward(c, c->enc, params, x, ws, c->B, true, z1, st))) return rc;
     const float* samples = at<float>(ws, c->ws_samples);
     float* mu = at<float>(ws, c->enc.act_off.back());
+    float* y_lin = at<float>(ws, c->dec.act_off.back());
+    const float* eps_param = c->off_eps >= 0 ? params + c->off_eps : nullptr;
+    const Layer& last = c->dec.layers.back();
+    if (!sig && !use_bf16(c, last.n_in, last.n_out)) {
+        // one decoder, exact f32 output layer: the ELBO's elementwise pass runs in that layer's epilogue -- its output never
+        // goes to HBM, dL/dx_hat lands where the backward pass expects it
+        ElboFuse ef{x, z2, eps_param, c->cfg.eps_cli, inv_bt, at<float>(ws, c->ws_eblk), 0, 0};
+        if ((rc = net_forward(c, c->dec, params, samples, ws, c->B, false, nullptr, st, &ef))) return rc;
+        if ((rc = launch_elbo_reduce(ef.part, ef.bm, ef.nbx, mu, at<float>(ws, c->ws_epart), c->B, c->L, c->Se, c->rows_per_esplit,
+                                     step_dev, st)))
+            return rc;
+        float* dsamp = at<float>(ws, c->ws_dsamp);
+        if ((rc = net_backward(c, c->dec, params, samples, y_lin, ws, dsamp, false, st, sink))) return rc;
+        if ((rc = launch_reparam_bwd(dsamp, mu, z1, at<float>(ws, c->ws_rpart), c->B, c->L, c->Se, c->rows_per_esplit, inv_bt, st)))
+            return rc;
+        return net_backward(c, c->enc, params, x, dsamp, ws, nullptr, false, st, sink);
+    }
     if ((rc = net_forward(c, c->dec, params, samples, ws, c->B, false, nullptr, st))) return rc;
     if (sig && (rc = net_forward(c, c->sig, params, samples, ws, c->B, false, nullptr, st))) return rc;
-    float* y_lin = at<float>(ws, c->dec.act_off.back());
     float* y_sig = sig ? at<float>(ws, c->sig.act_off.back()) : nullptr;
     ElboArgs e{};
     e.x = x; e.y_lin = y_lin; e.y_sig = y_sig; e.z2 = z2; e.mu = mu;
-    e.eps_param = c->off_eps >= 0 ? params + c->off_eps : nullptr;
+    e.eps_param = eps_param;
     e.eps_cli = c->cfg.eps_cli;
     e.d_lin = y_lin; e.d_sig = y_sig;
     e.partial = at<float>(ws, c->ws_epart);
@@ -272,7 +295,11 @@ int vaek_ctx_create(const vaek_config* cfg, vaek_ctx** out) {
         for (auto& l : n.layers) {
             // wide layers run 128 x 128 tiles (gemm_f32.hip) and want ~3 workgroups per CU; the rest 64-wide tiles
             const bool wide = l.n_in + 1 >= 128 && l.n_out >= 128;
-            const int tiles = wide ? ((l.n_in + 1 + 127) / 128) * ((l.n_out + 127) / 128) : ((l.n_in + 1 + 63) / 64) * ((l.n_out + 63) / 64);
+            // ... counted in the tile shape gemm_f32.hip's launch() picks: 128 x 128, 128 x 32 (n_out <= 32), 32 x 128 (n_in < 32)
+            const int tiles = wide ? ((l.n_in + 1 + 127) / 128) * ((l.n_out + 127) / 128)
+                            : l.n_out <= 32 ? (l.n_in + 1 + 127) / 128
+                            : l.n_in + 1 <= 32 ? (l.n_out + 127) / 128
+                            : ((l.n_in + 1 + 63) / 64) * ((l.n_out + 63) / 64);
             const int s_target = std::min(256, std::max(4, (wide ? 768 : 1024) / tiles));
             l.rows_per_split = std::max(64, (int)align_up((size_t)(c->B + s_target - 1) / s_target, 64));
             l.S = (c->B + l.rows_per_split - 1) / l.rows_per_split;
@@ -283,7 +310,7 @@ int vaek_ctx_create(const vaek_config* cfg, vaek_ctx** out) {
     if (c->enc.layers.size() + c->dec.layers.size() + c->sig.layers.size() > 32) {
         set_error("too many layers"); delete c; return VAEK_ERR_INVALID;
     }
-    c->rows_per_esplit = std::max(64, (int)align_up((size_t)(c->B + 1023) / 1024, 64));
+    c->rows_per_esplit = std::max(128, (int)align_up((size_t)(c->B + 1023) / 1024, 128));      // whole 64- and 128-row GEMM tiles
     c->Se = (c->B + c->rows_per_esplit - 1) / c->rows_per_esplit;
 
     size_t off = 0;
@@ -297,6 +324,8 @@ int vaek_ctx_create(const vaek_config* cfg, vaek_ctx** out) {
     c->ws_slabs = off; off = align_up(off + (size_t)c->S * slab_stride(c) * sizeof(float), 256);
     c->ws_epart = off; off = align_up(off + (size_t)c->Se * 4 * sizeof(float), 256);
     c->ws_rpart = off; off = align_up(off + (size_t)c->Se * c->L * sizeof(float), 256);
+    // {mse, d eps} per output tile of the decoder's last GEMM: at most (B/64) x (D/32) tiles in any of its tile shapes
+    c->ws_eblk = off; off = align_up(off + (size_t)((c->B + 63) / 64) * ((c->D + 31) / 32) * 2 * sizeof(float), 256);
     c->fused = !cfg->force_generic && fused_supported(c);
     c->ws_fused = off; off = align_up(off + fused_workspace_bytes(c), 256);
     c->ws_total = off;
@@ -400,7 +429,7 @@ int vaek_elbo_fwd_bwd(vaek_ctx* ctx, const float* x, const float* x_hat_lin, con
     }
     int rc = check_ws(ctx, workspace);
     if (rc) return rc;
-    const int rpe = std::max(64, (int)align_up((size_t)(rows + 1023) / 1024, 64));
+    const int rpe = std::max(128, (int)align_up((size_t)(rows + 1023) / 1024, 128));       // as vaek_ctx_create sizes the partials
     const int Se = (rows + rpe - 1) / rpe;
     if (Se > ctx->Se) { set_error("vaek_elbo_fwd_bwd: rows %d exceed this context's batch %d", rows, ctx->B); return VAEK_ERR_WORKSPACE; }
     const int64_t bt = batch_total > 0 ? batch_total : rows;

@@ -96,6 +96,37 @@ __global__ __launch_bounds__(256) void elbo_kernel(const ElboArgs a) {
     }
 }
 
+// Second half of the ELBO when its elementwise pass ran in the decoder's last GEMM (gemm_f32.hip, EPI_ELBO): split s sums
+// the {mse, d eps} pairs of the output tiles whose rows it owns (tile rows of `bm` rows, `nbx` tiles each; a split starts
+// on a tile row) and the mu^2 of its rows, and writes the same partial[s][4] elbo_kernel would have.  Fixed order.
+__global__ __launch_bounds__(256) void elbo_reduce_kernel(const float* part, int bm, int nbx, const float* mu, float* partial,
+                                                         int rows, int L, int rows_per_split, int32_t* step_dev) {
+    __shared__ float red[8];
+    const int s = blockIdx.x;
+    const long long r0 = (long long)s * rows_per_split, r1 = min((long long)rows, r0 + rows_per_split);
+    float mse = 0.f, deps = 0.f, musq = 0.f;
+    if (r0 < r1) {
+        const long long t0 = r0 / bm * nbx, t1 = (r1 + bm - 1) / bm * nbx;
+        for (long long t = t0 + threadIdx.x; t < t1; t += blockDim.x) { mse += part[2 * t]; deps += part[2 * t + 1]; }
+        for (long long e = r0 * L + threadIdx.x; e < r1 * L; e += blockDim.x) { const float m = mu[e]; musq += m * m; }
+    }
+    const float t_mse = block_sum(mse, red), t_deps = block_sum(deps, red), t_musq = block_sum(musq, red);
+    if (threadIdx.x == 0) {
+        float* p = partial + (long long)s * 4;
+        p[0] = t_mse; p[1] = t_musq; p[2] = t_deps; p[3] = 0.f;
+        if (s == 0 && step_dev) step_dev[0] += 1;
+    }
+}
+
+int launch_elbo_reduce(const float* part, int bm, int nbx, const float* mu, float* partial, int rows, int L, int S,
+                       int rows_per_split, int32_t* step_dev, hipStream_t st) {
+    if (rows_per_split % bm != 0) { set_error("elbo reduce: split of %d rows does not start on %d-row tiles", rows_per_split, bm); return VAEK_ERR_INVALID; }
+    ProfScope ps("elbo_reduce", st);
+    launch_k(ps, elbo_reduce_kernel, dim3(S), dim3(256), 0, st, part, bm, nbx, mu, partial, rows, L, rows_per_split, step_dev);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
 int launch_elbo(const ElboArgs& a, hipStream_t st) {
     const bool sig = a.y_sig != nullptr, grads = a.d_lin != nullptr;
     ProfScope ps("elbo", st);

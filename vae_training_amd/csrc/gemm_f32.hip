@@ -23,7 +23,7 @@ constexpr int NT = 256;      // BK (k-tile depth) is a template parameter: 16, o
 // dW|db of an input layer with a handful of features).  With a 64-wide tile a 20-column output keeps half
 // of each block's MFMAs busy on columns nobody stores.
 
-enum { EPI_FWD = 0, EPI_REPARAM = 1, EPI_DX = 2, EPI_DW = 3 };
+enum { EPI_FWD = 0, EPI_REPARAM = 1, EPI_DX = 2, EPI_DW = 3, EPI_ELBO = 4 };
 
 struct GemmArgs {
     const float* A; const float* B; float* C;
@@ -36,6 +36,10 @@ struct GemmArgs {
     const float* lv;          // REPARAM: logvar_e [N]
     int accumulate;
     int k_per_split; long long slab_stride;   // DW
+    // ELBO (decoder's last layer, networks.py:80-83 + 94-98 fused into its epilogue): aux = data batch x [M, ldc],
+    // aux2 = z2 [M, ldc]; C receives dL/dx_hat instead of the layer output; part[(by * nbx + bx) * 2] = this tile's
+    // {sum of mse terms, sum of d eps terms}
+    const float* aux2; float* part; const float* eps_param; float eps_cli, inv_bt;
 };
 
 // Operand tile = T (mn) x BK (k) floats, staged k-major into LDS rows of T + 4 floats.
@@ -180,12 +184,17 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
         }
     }
     // C/D map of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float e_mse = 0.f, e_deps = 0.f, e_inv_var = 0.f, e_sigma = 0.f, e_dscale = 0.f;
+    if (EPI == EPI_ELBO) {
+        const float eps = g.eps_param ? g.eps_param[0] * g.eps_cli : g.eps_cli;
+        e_inv_var = expf(-eps); e_sigma = expf(0.5f * eps); e_dscale = e_inv_var * g.inv_bt;
+    }
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
         const int col = n0 + (wn * TN + jn) * 32 + (lane & 31);
         if (col >= g.N) continue;
         float bias = 0.f, sdev = 0.f;
-        if (EPI == EPI_FWD || EPI == EPI_REPARAM) bias = g.bias ? g.bias[col] : 0.f;
+        if (EPI == EPI_FWD || EPI == EPI_REPARAM || EPI == EPI_ELBO) bias = g.bias ? g.bias[col] : 0.f;
         if (EPI == EPI_REPARAM) sdev = expf(0.5f * g.lv[col]);
         float* C = g.C;
         if (EPI == EPI_DW) C += (long long)bz * g.slab_stride;
@@ -209,23 +218,45 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
                     if (g.relu) v = g.aux[o] > 0.f ? v : 0.f;
                     if (g.accumulate) v += C[o];
                     C[o] = v;
+                } else if (EPI == EPI_ELBO) {
+                    const float z = g.aux2[o];
+                    const float rr = (v + bias) + e_sigma * z - g.aux[o];        // x_hat - x, x_hat = y + z2 e^{eps/2}
+                    const float q = rr * rr * e_inv_var;
+                    e_mse += 0.5f * q;
+                    e_deps += -0.5f * q + 0.5f * e_sigma * z * rr * e_inv_var;
+                    C[o] = rr * e_dscale;
                 } else {
                     C[o] = v;
                 }
             }
         }
     }
+    if (EPI == EPI_ELBO) {      // this tile's two sums, fixed order: lanes by xor-shuffle, then the four waves in order
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { e_mse += __shfl_xor(e_mse, o, 64); e_deps += __shfl_xor(e_deps, o, 64); }
+        __syncthreads();                                   // the operand tiles in As are dead
+        if (lane == 0) { As[2 * wave] = e_mse; As[2 * wave + 1] = e_deps; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float* p = g.part + ((long long)by * gridDim.x + bx) * 2;
+            p[0] = ((As[0] + As[2]) + As[4]) + As[6];
+            p[1] = ((As[1] + As[3]) + As[5]) + As[7];
+        }
+    }
 }
+
+static thread_local int g_last_bm = 0, g_last_nbx = 0;      // tile rows / tile columns of the last launch (ELBO partials)
 
 template <bool A_KCONT, bool B_KCONT, int EPI, int WM, int WN, int BK, int TM = 1, int TN = 1>
 static int launch_shape(const GemmArgs& g, int splits, hipStream_t st) {
     ProfScope ps(EPI == EPI_FWD ? "gemm_f32_fwd" : EPI == EPI_REPARAM ? "gemm_f32_fwd_reparam"
-                 : EPI == EPI_DX ? "gemm_f32_dx" : "gemm_f32_dw", st);
+                 : EPI == EPI_DX ? "gemm_f32_dx" : EPI == EPI_ELBO ? "gemm_f32_fwd_elbo" : "gemm_f32_dw", st);
     dim3 grid((g.N + 32 * WN * TN - 1) / (32 * WN * TN), (g.M + 32 * WM * TM - 1) / (32 * WM * TM), splits);
     if (grid.y > 65535u || grid.z > 65535u) {
         set_error("gemm grid too large (M=%d N=%d splits=%d)", g.M, g.N, splits);
         return VAEK_ERR_INVALID;
     }
+    g_last_bm = 32 * WM * TM; g_last_nbx = (int)grid.x;
     launch_k(ps, (gemm_f32_kernel<A_KCONT, B_KCONT, EPI, WM, WN, BK, TM, TN>), grid, dim3(NT), 0, st, g);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
@@ -257,6 +288,21 @@ int launch_dense_fwd(const float* x, const float* w, const float* b, float* y, i
     g.A = x; g.B = w; g.C = y; g.M = rows; g.N = n_out; g.K = n_in;
     g.lda = n_in; g.ldb = n_out; g.ldc = n_out; g.a_mem = 0; g.bias = b; g.relu = relu;
     return launch<true, false, EPI_FWD>(g, 1, st);
+}
+
+// The decoder's last Dense with the ELBO's elementwise pass in its epilogue: d_out receives dL/dx_hat (what the backward
+// pass wants in that buffer anyway) and `part` one {mse, d eps} pair per output tile; *bm / *nbx tell the reducer
+// (launch_elbo_reduce) how the tiles map to rows.  Saves writing and re-reading the B x D layer output.
+int launch_dense_fwd_elbo(const float* h, const float* w, const float* b, float* d_out, const float* x, const float* z2,
+                          const float* eps_param, float eps_cli, float inv_bt, float* part, int rows, int n_in, int n_out,
+                          int* bm, int* nbx, hipStream_t st) {
+    GemmArgs g{};
+    g.A = h; g.B = w; g.C = d_out; g.M = rows; g.N = n_out; g.K = n_in;
+    g.lda = n_in; g.ldb = n_out; g.ldc = n_out; g.bias = b;
+    g.aux = x; g.aux2 = z2; g.part = part; g.eps_param = eps_param; g.eps_cli = eps_cli; g.inv_bt = inv_bt;
+    const int rc = launch<true, false, EPI_ELBO>(g, 1, st);
+    *bm = g_last_bm; *nbx = g_last_nbx;
+    return rc;
 }
 
 int launch_dense_fwd_reparam(const float* x, const float* w, const float* b, float* mu, float* samples,

@@ -95,7 +95,7 @@ struct vaek_ctx {
     int S, rows_per_split, Se, rows_per_esplit;
     bool fused;                      // fused small-model path available and selected
     // workspace layout (bytes)
-    size_t ws_samples, ws_dsamp, ws_gbuf0, ws_gbuf1, ws_slabs, ws_epart, ws_rpart, ws_fused, ws_total;
+    size_t ws_samples, ws_dsamp, ws_gbuf0, ws_gbuf1, ws_slabs, ws_epart, ws_rpart, ws_eblk, ws_fused, ws_total;
     int max_width;
     int n_cu;
     vaek::Comm comm;
@@ -141,6 +141,11 @@ struct ElboArgs {
     int32_t* step_dev;        // incremented by block 0 (may be nullptr)
 };
 int launch_elbo(const ElboArgs& a, hipStream_t st);
+int launch_elbo_reduce(const float* part, int bm, int nbx, const float* mu, float* partial, int rows, int L, int S,
+                       int rows_per_split, int32_t* step_dev, hipStream_t st);
+int launch_dense_fwd_elbo(const float* h, const float* w, const float* b, float* d_out, const float* x, const float* z2,
+                          const float* eps_param, float eps_cli, float inv_bt, float* part, int rows, int n_in, int n_out,
+                          int* bm, int* nbx, hipStream_t st);
 // dmu = dsamp + mu * inv_bt (in place on dsamp); partial[s][l] = sum_rows dsamp * z1
 int launch_reparam_bwd(float* dsamp, const float* mu, const float* z1, float* partial,
                        int rows, int L, int S, int rows_per_split, float inv_bt, hipStream_t st);
