@@ -92,53 +92,62 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
     // ---- inputs of this wave's 64 samples, in accumulator layout, straight from HBM ----------------
     float xv[NSUB][NDB][4], z2v[NSUB][NDB][4], z1v[NSUB][NLB][4];
     bool valid[NSUB];
+    // Every load is UNCONDITIONAL, from a clamped row (and, in the padded variants, a clamped column), and nothing is
+    // zeroed afterwards: a sample past the batch end reads row B-1 again and a padded column reads column D-1 / L-1 --
+    // finite values whose every contribution is already masked downstream (rr, dmu, mu^2 by `valid`; padded columns by
+    // zero weights / zero e^{lv/2} and by rows of the gradient image nobody reads).  With the loads under `if (valid)`
+    // hipcc merged each conditionally loaded float4 into its zero-initialised registers INSIDE the branch, i.e. put an
+    // `s_waitcnt vmcnt` into every sub-tile's block, and a zeroing pass after the loads waits for all of them.  Now all 56
+    // loads of a wave (24 parameter, 32 input) leave before the first wait.  Measured: 8.76 -> 8.64 us per launch only --
+    // the load phase is bandwidth-, not latency-bound, and at 260 VGPRs hipcc still copies the z1 / z2 registers away early
+    // enough that the first products wait for ~3/4 of the bytes.
     auto load_inputs = [&](int tile) {
+        const float* px[NSUB]; const float* pz2[NSUB]; const float* pz1[NSUB];
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) {
             const long long b = (long long)tile * G::TILE + wave * 64 + s * 16 + j;
             valid[s] = b < a.B;
-            const float* px = a.x + b * D; const float* pz2 = a.z2 + b * D; const float* pz1 = a.z1 + b * L;
+            const long long bc = valid[s] ? b : (long long)a.B - 1;
+            px[s] = a.x + bc * D; pz2[s] = a.z2 + bc * D; pz1[s] = a.z1 + bc * L;
+        }
+        // Issue order = order of first use: x of all four sub-tiles (the mu products can start when a quarter of the
+        // tile's bytes have landed), then z1 (reparameterisation), then z2 (residual) -- loads return in order.
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s)
 #pragma unroll
             for (int db = 0; db < NDB; ++db) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { xv[s][db][r] = 0.f; z2v[s][db][r] = 0.f; }
-                if (!valid[s]) continue;
                 if (AD::full(db) && vecD) {
-                    const int d0 = AD::feat(db, g, 0);
-                    if (d0 < D) {
-                        const float4 u = *reinterpret_cast<const float4*>(px + d0);
-                        const float4 w = *reinterpret_cast<const float4*>(pz2 + d0);
-                        xv[s][db][0] = u.x; xv[s][db][1] = u.y; xv[s][db][2] = u.z; xv[s][db][3] = u.w;
-                        z2v[s][db][0] = w.x; z2v[s][db][1] = w.y; z2v[s][db][2] = w.z; z2v[s][db][3] = w.w;
-                    }
+                    const float4 u = *reinterpret_cast<const float4*>(px[s] + min(AD::feat(db, g, 0), D - 4));
+                    xv[s][db][0] = u.x; xv[s][db][1] = u.y; xv[s][db][2] = u.z; xv[s][db][3] = u.w;
                 } else {
 #pragma unroll
-                    for (int r = 0; r < AD::nreg(db); ++r) {
-                        const int d = AD::feat(db, g, r);
-                        if (d < D) { xv[s][db][r] = px[d]; z2v[s][db][r] = pz2[d]; }
-                    }
+                    for (int r = 0; r < 4; ++r) xv[s][db][r] = r < AD::nreg(db) ? px[s][min(AD::feat(db, g, r), D - 1)] : 0.f;
                 }
             }
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s)
 #pragma unroll
             for (int lb = 0; lb < NLB; ++lb) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) z1v[s][lb][r] = 0.f;
-                if (!valid[s]) continue;
                 if (AL::full(lb) && vecL) {
-                    const int l0 = AL::feat(lb, g, 0);
-                    if (l0 < L) {
-                        const float4 u = *reinterpret_cast<const float4*>(pz1 + l0);
-                        z1v[s][lb][0] = u.x; z1v[s][lb][1] = u.y; z1v[s][lb][2] = u.z; z1v[s][lb][3] = u.w;
-                    }
+                    const float4 u = *reinterpret_cast<const float4*>(pz1[s] + min(AL::feat(lb, g, 0), L - 4));
+                    z1v[s][lb][0] = u.x; z1v[s][lb][1] = u.y; z1v[s][lb][2] = u.z; z1v[s][lb][3] = u.w;
                 } else {
 #pragma unroll
-                    for (int r = 0; r < AL::nreg(lb); ++r) {
-                        const int l = AL::feat(lb, g, r);
-                        if (l < L) z1v[s][lb][r] = pz1[l];
-                    }
+                    for (int r = 0; r < 4; ++r) z1v[s][lb][r] = r < AL::nreg(lb) ? pz1[s][min(AL::feat(lb, g, r), L - 1)] : 0.f;
                 }
             }
-        }
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                if (AD::full(db) && vecD) {
+                    const float4 w = *reinterpret_cast<const float4*>(pz2[s] + min(AD::feat(db, g, 0), D - 4));
+                    z2v[s][db][0] = w.x; z2v[s][db][1] = w.y; z2v[s][db][2] = w.z; z2v[s][db][3] = w.w;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) z2v[s][db][r] = r < AD::nreg(db) ? pz2[s][min(AD::feat(db, g, r), D - 1)] : 0.f;
+                }
+            }
     };
 #if defined(VAEK_ABLATE) && VAEK_ABLATE == 2   // diagnostic (tools/ablate.sh): the same bytes as wide, fully coalesced 16-byte loads
     {
@@ -156,13 +165,15 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
         return;
     }
 #endif
-    load_inputs(blockIdx.x);
-
     // ---- weights as MFMA A operands (lane = output row ai, k group akg), zero outside [D, L] -------
     // row ai of a block <-> (g', r') = (ai >> 2, ai & 3)
     auto latrow = [&](int lb) { return AL::feat(lb, ai >> 2, ai & 3); };
     auto datrow = [&](int db) { return AD::feat(db, ai >> 2, ai & 3); };
     float wmu[NLB][NDB][4], wy[NDB][NLB][4], wg[NLB][NDB][4], wys[SIG ? NDB : 1][NLB][4], wgs[SIG ? NLB : 1][NDB][4];
+    // Like the inputs, every parameter load is unconditional (index 0 where the operand is padding) and the zeroing
+    // selects come AFTER the input loads have been issued: a select inside the load sequence is an s_waitcnt there.
+    auto w_ok1 = [&](int lb, int db, int s) { return s < AD::nreg(db) && (ai & 3) < AL::nreg(lb) && latrow(lb) < L && AD::feat(db, akg, s) < D; };
+    auto w_ok2 = [&](int db, int lb, int s) { return s < AL::nreg(lb) && (ai & 3) < AD::nreg(db) && datrow(db) < D && AL::feat(lb, akg, s) < L; };
 #pragma unroll
     for (int lb = 0; lb < NLB; ++lb)
 #pragma unroll
@@ -171,15 +182,15 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
             for (int s = 0; s < 4; ++s) {
                 // mu: out row = latent latrow(lb), k = data dim feat(db, akg, s);  g: same roles, weights Wd
                 const int lo = latrow(lb), dk = AD::feat(db, akg, s);
-                const bool ok = s < AD::nreg(db) && (ai & 3) < AL::nreg(lb) && lo < L && dk < D;
-                wmu[lb][db][s] = ok ? params[dk * L + lo] : 0.f;
-                wg[lb][db][s] = ok ? params[off_wd + lo * D + dk] : 0.f;
-                if (SIG) wgs[lb][db][s] = ok ? params[off_ws + lo * D + dk] : 0.f;
+                const bool ok = w_ok1(lb, db, s);
+                wmu[lb][db][s] = params[ok ? dk * L + lo : 0];
+                wg[lb][db][s] = params[ok ? off_wd + lo * D + dk : 0];
+                if (SIG) wgs[lb][db][s] = params[ok ? off_ws + lo * D + dk : 0];
                 // y: out row = data dim datrow(db), k = latent feat(lb, akg, s)
                 const int dout = datrow(db), lk = AL::feat(lb, akg, s);
-                const bool ok2 = s < AL::nreg(lb) && (ai & 3) < AD::nreg(db) && dout < D && lk < L;
-                wy[db][lb][s] = ok2 ? params[off_wd + lk * D + dout] : 0.f;
-                if (SIG) wys[db][lb][s] = ok2 ? params[off_ws + lk * D + dout] : 0.f;
+                const bool ok2 = w_ok2(db, lb, s);
+                wy[db][lb][s] = params[ok2 ? off_wd + lk * D + dout : 0];
+                if (SIG) wys[db][lb][s] = params[ok2 ? off_ws + lk * D + dout : 0];
             }
     // per-lane constants in accumulator layout (group g, register r)
     float c_be[NLB][4], c_sd[NLB][4], c_bd[NDB][4], c_bs[SIG ? NDB : 1][4];
@@ -189,8 +200,8 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
         for (int r = 0; r < 4; ++r) {
             const int l = AL::feat(lb, g, r);
             const bool ok = r < AL::nreg(lb) && l < L;
-            c_be[lb][r] = ok ? params[off_be + l] : 0.f;
-            c_sd[lb][r] = ok ? expf(0.5f * params[off_epsp + l]) : 0.f;      // e^{lv/2}, networks.py:73
+            c_be[lb][r] = params[ok ? off_be + l : 0];
+            c_sd[lb][r] = params[ok ? off_epsp + l : 0];                      // logvar_e now, e^{lv/2} below
         }
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
@@ -198,10 +209,43 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
         for (int r = 0; r < 4; ++r) {
             const int d = AD::feat(db, g, r);
             const bool ok = r < AD::nreg(db) && d < D;
-            c_bd[db][r] = ok ? params[off_bd + d] : 0.f;
-            if (SIG) c_bs[db][r] = ok ? params[off_bs + d] : 0.f;
+            c_bd[db][r] = params[ok ? off_bd + d : 0];
+            if (SIG) c_bs[db][r] = params[ok ? off_bs + d : 0];
         }
-    const float eps = a.off_eps >= 0 ? params[a.off_eps] * a.eps_cli : a.eps_cli;
+    const float eps_raw = a.off_eps >= 0 ? params[a.off_eps] : 0.f;
+
+    // inputs AFTER the weights: loads return in order, and the first product needs the weights and x only
+    load_inputs(blockIdx.x);
+    __builtin_amdgcn_sched_barrier(0);        // nothing that WAITS for a parameter may be scheduled above the input loads
+
+#pragma unroll
+    for (int lb = 0; lb < NLB; ++lb)
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bool ok = w_ok1(lb, db, s), ok2 = w_ok2(db, lb, s);
+                wmu[lb][db][s] = ok ? wmu[lb][db][s] : 0.f; wg[lb][db][s] = ok ? wg[lb][db][s] : 0.f;
+                wy[db][lb][s] = ok2 ? wy[db][lb][s] : 0.f;
+                if (SIG) { wgs[lb][db][s] = ok ? wgs[lb][db][s] : 0.f; wys[db][lb][s] = ok2 ? wys[db][lb][s] : 0.f; }
+            }
+#pragma unroll
+    for (int lb = 0; lb < NLB; ++lb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = r < AL::nreg(lb) && AL::feat(lb, g, r) < L;
+            c_be[lb][r] = ok ? c_be[lb][r] : 0.f;
+            c_sd[lb][r] = ok ? expf(0.5f * c_sd[lb][r]) : 0.f;                // e^{lv/2}, networks.py:73
+        }
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = r < AD::nreg(db) && AD::feat(db, g, r) < D;
+            c_bd[db][r] = ok ? c_bd[db][r] : 0.f;
+            if (SIG) c_bs[db][r] = ok ? c_bs[db][r] : 0.f;
+        }
+    const float eps = a.off_eps >= 0 ? eps_raw * a.eps_cli : a.eps_cli;
     const float inv_var = expf(-eps), sigma = expf(0.5f * eps);
     const float dscale = inv_var * a.inv_bt;
 
@@ -240,8 +284,10 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
         return;
     }
 #endif
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        if (tile != (int)blockIdx.x) load_inputs(tile);
+    // (the next tile's inputs are fetched at the END of the body, not under an `if` at its top: with the reload on a side
+    // path into the loop header hipcc's waitcnt bookkeeping merged two load histories and made the first product wait for
+    // nearly every load; at B = 65 536 the body runs once per workgroup)
+    for (int tile = blockIdx.x; tile < a.ntiles;) {
         VAEK_MSTAMP(1);
         // ---- mu^T = We^T x^T + be : the four 16-sample sub-tiles are independent MFMA chains ----------
         f32x4 mu[NSUB][NLB];
@@ -409,6 +455,8 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        tile += gridDim.x;
+        if (tile < a.ntiles) load_inputs(tile);
     }
     VAEK_MSTAMP(5);
 
