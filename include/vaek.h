@@ -205,7 +205,8 @@ int vaek_make_batch_next(vaek_ctx* ctx, int32_t kind, const float* A, int32_t dd
 /* vaek_train_step on (x, z1, z2) AND vaek_make_batch_next into (x_next, z1_next, z2_next) -- the loop body of
  * model.py:221-222 with the draw for step n+1 taken off the critical path.  On the fused path the generator's work
  * items ride in the finalize launch (which by itself occupies 9 of 256 CUs): still two launches per step, one
- * stream, no cross-queue dependency.  Elsewhere it is the two calls back to back.  Results are bit-identical to the
+ * stream, no cross-queue dependency; a batch that fits one workgroup (<= 256 rows, single GPU) is ONE launch, the draw on
+ * its workgroups 1.. .  Elsewhere it is the two calls back to back.  Results are bit-identical to the
  * separate calls.  The next batch has ctx.batch rows and must not alias the current one. */
 int vaek_train_step_gen(vaek_ctx* ctx, float* params, float* grads, float* m, float* v, int32_t* step_dev, const float* x,
                         const float* z1, const float* z2, float lr, void* workspace, int32_t kind, const float* A, int32_t dd,

@@ -128,7 +128,7 @@ def test_make_batch_next_is_make_batch_with_a_self_advancing_step(rows):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,hidden,B", [("linear_gaussian", (), 1000), ("linear_gaussian", (), 65536), ("sigmoid", (), 300),
+@pytest.mark.parametrize("kind,hidden,B", [("linear_gaussian", (), 100), ("linear_gaussian", (), 256), ("linear_gaussian", (), 1000), ("linear_gaussian", (), 65536), ("sigmoid", (), 300),
                                             ("sphere", (64,), 500)])
 def test_train_step_gen_is_make_batch_next_plus_train_step(kind, hidden, B):
     """vaek_train_step_gen (next batch drawn by spare blocks of the finalize launch on the fused path; two launches

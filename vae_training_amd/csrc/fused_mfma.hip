@@ -25,6 +25,7 @@
 // operands.  Bias / epsilon_p gradients are column sums: accumulated per lane, reduced over the 16
 // lanes of a row with DPP-class shuffles once per kernel.
 #include "comm_dev.h"
+#include "rng_dev.h"
 #include "vaek_internal.h"
 
 namespace vaek {
@@ -74,8 +75,17 @@ struct MGeom {
     static constexpr int LDS_FLOATS = (T_FLOATS > R_FLOATS ? T_FLOATS : R_FLOATS);
 };
 
-template <int DP, int LP, bool SIG, bool EXACT>
+// SINGLE: the one-workgroup (batch <= 256 rows) form that finalizes itself -- a separate instantiation, so that the
+// metric's multi-workgroup kernel is compiled exactly as if this form did not exist (folded into one kernel behind a
+// runtime flag it cost that kernel 0.35 us per launch).
+template <int DP, int LP, bool SIG, bool EXACT, bool SINGLE>
 __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __restrict__ params, const FusedArgs a) {
+    if (SINGLE && blockIdx.x > 0) {      // single-launch step with a batch to draw: workgroups 1.. are K7's work items
+        const unsigned gstep = make_batch_step(a.gen);
+        make_batch_items(a.gen, gstep, (long long)(blockIdx.x - 1) * 256 + threadIdx.x);
+        make_batch_advance(a.gen, gstep, blockIdx.x == 1 && threadIdx.x == 0);
+        return;
+    }
     using G = MGeom<DP, LP, SIG>;
     using AD = typename G::AD;
     using AL = typename G::AL;
@@ -525,8 +535,7 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
         for (int w = 0; w < G::NW; ++w) v += T[w * G::R_PER_WAVE + G::NBLK * 256 + k];
         return v;
     };
-    float* out = a.partials + (long long)blockIdx.x * a.pstride;
-    for (int idx = t; idx < a.P + kExtra; idx += 256) {
+    auto batch_sum = [&](int idx) -> float {            // output idx of the flat gradient, summed over this workgroup's samples
         float v = 0.f;
         if (idx < off_be) v = fetch(2, idx / L, idx % L);                              // dWe = x^T dmu
         else if (idx < off_wd) v = fetch_cs(G::NB1 + idx - off_be);                    // dbe = 1^T dmu
@@ -536,17 +545,74 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
         else if (SIG && idx < off_bs + D) v = fetch_cs(DP + idx - off_bs);
         else if (idx >= off_epsp && idx < off_epsp + L) v = fetch_cs(G::NB1 + LP + idx - off_epsp);   // sum g*z1
         else if (idx >= a.P && idx < a.P + 3) v = fetch_cs(G::NCS + idx - a.P);
-        out[idx] = v;
+        return v;
+    };
+    if (!SINGLE) {
+        float* out = a.partials + (long long)blockIdx.x * a.pstride;
+        for (int idx = t; idx < a.P + kExtra; idx += 256) out[idx] = batch_sum(idx);
+        VAEK_MSTAMP(6);
+        if (blockIdx.x == 0 && t == 0 && a.step_dev) a.step_dev[0] += 1;
+        return;
     }
+    // ---- single-launch step: this workgroup holds the whole batch, so its sums ARE the batch sums, and what
+    // fused_finalize_kernel does in a second launch for bigger batches happens here: closed-form KL / log-variance terms,
+    // the three means, Adam, the step counter, the loss ring.  All reads of params come before the barrier, all writes
+    // after it.  (The two forms are never mixed for one context: grid == 1 always takes this one.)
+    constexpr int PMAX = DP * LP + LP + (SIG ? 2 : 1) * (LP * DP + DP) + LP + 1 + kExtra;
+    constexpr int NOUT = (PMAX + 255) / 256;
+    const int tstep = a.step_dev[0] + 1;
+    const float s_mse_t = fetch_cs(G::NCS + 0), s_musq_t = fetch_cs(G::NCS + 1), s_deps_t = fetch_cs(G::NCS + 2);
+    float gk[NOUT], pk[NOUT], mk[NOUT], vk[NOUT];
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) {
+        const int idx = t + 256 * k;
+        gk[k] = 0.f; pk[k] = 0.f; mk[k] = 0.f; vk[k] = 0.f;
+        if (idx >= a.P + kExtra) continue;
+        float gq_ = batch_sum(idx);
+        if (idx < a.P) { pk[k] = a.params_rw[idx]; mk[k] = a.m[idx]; vk[k] = a.v[idx]; }
+        if (idx >= off_epsp && idx < off_epsp + L) {
+            const float lv = pk[k];
+            gq_ = 0.5f * expf(0.5f * lv) * gq_ - 0.5f * (1.f - expf(lv)) * a.rows_over_bt;
+        } else if (idx == a.off_eps) {
+            gq_ = a.eps_cli * (s_deps_t + 0.5f * a.rows * (float)D) * a.inv_bt;
+        } else if (idx >= a.P) {
+            if (idx < a.P + 3) {
+                float klc = 0.f;
+                for (int l = 0; l < L; ++l) { const float lv = a.params_rw[off_epsp + l]; klc += 1.f + lv - expf(lv); }
+                const float eps_s = a.off_eps >= 0 ? a.params_rw[a.off_eps] * a.eps_cli : a.eps_cli;
+                const float dkl = (0.5f * s_musq_t - 0.5f * a.rows * klc) * a.inv_bt;
+                const float mse = (s_mse_t + 0.5f * a.rows * (float)D * (kLog2Pi + eps_s)) * a.inv_bt;
+                gq_ = idx == a.P ? dkl + mse : (idx == a.P + 1 ? dkl : mse);
+            } else {
+                gq_ = 0.f;
+            }
+        }
+        gk[k] = gq_;
+    }
+    __syncthreads();
+    const float bc1 = -expm1f((float)tstep * -0.10536051565782628f);
+    const float bc2 = -expm1f((float)tstep * -0.0010005003335835335f);
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) {
+        const int idx = t + 256 * k;
+        if (idx >= a.P + kExtra) continue;
+        a.grads[idx] = gk[k];
+        if (idx == a.P && a.loss_hist) a.loss_hist[(long long)(tstep - 1) % a.loss_hist_cap] = gk[k];
+        if (idx < a.P) {
+            adam_apply_f(pk[k], gk[k], mk[k], vk[k], a.lr, bc1, bc2);
+            a.params_rw[idx] = pk[k]; a.m[idx] = mk[k]; a.v[idx] = vk[k];
+        }
+    }
+    if (t == 0) a.step_dev[0] = tstep;
     VAEK_MSTAMP(6);
-    if (blockIdx.x == 0 && t == 0 && a.step_dev) a.step_dev[0] += 1;
 }
 
 // ---- variant table ---------------------------------------------------------------------------------
 typedef void (*MfmaKernel)(const float*, const FusedArgs);
-struct MfmaVariant { int dp, lp, sig, exact; MfmaKernel fn; size_t lds_bytes; };
+struct MfmaVariant { int dp, lp, sig, exact; MfmaKernel fn, fn_single; size_t lds_bytes; };
 #define VAEK_MFMA(DP, LP, SIG, EXACT) \
-    {DP, LP, SIG, EXACT, fused_linear_mfma_kernel<DP, LP, (SIG) != 0, (EXACT) != 0>, sizeof(float) * MGeom<DP, LP, (SIG) != 0>::LDS_FLOATS}
+    {DP, LP, SIG, EXACT, fused_linear_mfma_kernel<DP, LP, (SIG) != 0, (EXACT) != 0, false>, \
+     fused_linear_mfma_kernel<DP, LP, (SIG) != 0, (EXACT) != 0, true>, sizeof(float) * MGeom<DP, LP, (SIG) != 0>::LDS_FLOATS}
 
 static const MfmaVariant kMfmaVariants[] = {
     // exact shapes of seed_linpadding_expts.sh (the metric's configuration first)
@@ -578,15 +644,16 @@ int fused_mfma_launch(const vaek_ctx* c, const float* params, const void* args_v
     const MfmaVariant* var = pick_mfma(c);
     if (!var) { set_error("mfma fused path not available"); return VAEK_ERR_INVALID; }
     const FusedArgs& a = *static_cast<const FusedArgs*>(args_void);
-    static thread_local const void* lds_set[sizeof(kMfmaVariants) / sizeof(kMfmaVariants[0])] = {};
+    static thread_local const void* lds_set[2][sizeof(kMfmaVariants) / sizeof(kMfmaVariants[0])] = {};
     const size_t vi = var - kMfmaVariants;
-    if (var->lds_bytes > 64 * 1024 && lds_set[vi] == nullptr) {
-        VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)var->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)var->lds_bytes));
-        lds_set[vi] = (const void*)var->fn;
+    const MfmaKernel fn = a.single ? var->fn_single : var->fn;
+    if (var->lds_bytes > 64 * 1024 && lds_set[a.single ? 1 : 0][vi] == nullptr) {
+        VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)var->lds_bytes));
+        lds_set[a.single ? 1 : 0][vi] = (const void*)fn;
     }
     {
-        ProfScope ps("fused_linear_mfma", st);
-        launch_k(ps, var->fn, dim3(grid), dim3(256), var->lds_bytes, st, params, a);
+        ProfScope ps(a.single ? "fused_linear_mfma_single" : "fused_linear_mfma", st);
+        launch_k(ps, fn, dim3(grid), dim3(256), var->lds_bytes, st, params, a);
     }
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;

@@ -398,11 +398,6 @@ struct FusedFinArgs {
     float* loss_hist; long long loss_hist_cap;    // optional: loss of Adam step t -> loss_hist[(t-1) % cap]
 };
 
-__device__ __forceinline__ void adam_apply_f(float& p, float g, float& m, float& v, float lr, float bc1, float bc2) {
-    m = kAdamB1 * m + (float)(1.0 - 0.9) * g;
-    v = kAdamB2 * v + (float)(1.0 - 0.999) * g * g;
-    p = p - lr * (m / bc1) / (sqrtf(v / bc2) + kAdamEps);
-}
 
 // block b covers outputs [n - 64(b+1), n - 64b): the LAST 64 (epsilon_p, epsilon and the three
 // scalar sums, which need each other) always sit together in block 0.  1024 threads = 64 outputs x
@@ -575,6 +570,17 @@ int fused_train_step(vaek_ctx* c, float* params, float* grads, float* m, float* 
     a.off_epsp = (int)c->off_epsp; a.off_eps = (int)c->off_eps; a.P = (int)c->P;
     a.step_dev = step_dev;
     a.stamps = c->dbg_stamps;
+    if (use_mfma(c) && grid == 1 && apply_adam && !exchange && c->cfg.world == 1) {
+        // the whole batch is one workgroup's tile: ONE launch (fused_mfma.hip, single-launch step); with a batch to draw,
+        // the generator's work items are workgroups 1.. of the same launch
+        a.single = 1;
+        a.grads = grads; a.params_rw = params; a.m = m; a.v = v; a.lr = lr;
+        a.rows_over_bt = (float)((double)c->B / (double)c->Bt); a.rows = (float)c->B;
+        a.loss_hist = c->loss_hist; a.loss_hist_cap = c->loss_hist_cap;
+        int launch_grid = 1;
+        if (gen) { a.has_gen = 1; a.gen = *gen; launch_grid += (int)((make_batch_item_count(*gen) + 255) / 256); }
+        return fused_mfma_launch(c, params, &a, launch_grid, st);
+    }
     if (use_mfma(c)) {
         int rc = fused_mfma_launch(c, params, &a, grid, st);
         if (rc) return rc;

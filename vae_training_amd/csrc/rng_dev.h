@@ -146,7 +146,7 @@ __device__ __forceinline__ void make_batch_advance(const BatchArgs& a, unsigned 
     if (a.counter && first_thread) a.counter[a.which ^ 1] = (int32_t)(step + 1);
 }
 
-inline long long make_batch_item_count(const BatchArgs& a) {
+__host__ __device__ inline long long make_batch_item_count(const BatchArgs& a) {
     return (a.x ? (long long)a.rows * ((a.D + 3) / 4) : 0) + (a.z1 ? (long long)a.rows * ((a.L + a.D + 3) / 4) : 0);
 }
 

@@ -183,20 +183,16 @@ int launch_sum_slabs(const float* slabs, int64_t stride, int S, float* out, int6
 struct CommDev;
 CommDev comm_dev(const vaek_ctx* c, int region);
 
-// ---- fused_small.hip / fused_mfma.hip: arguments of the fused linear-VAE kernels ----------------
-struct FusedArgs {
-    const float* x; const float* z1; const float* z2;
-    float* partials; int pstride;      // [grid][pstride]
-    int B, D, L, ntiles;
-    float inv_bt, eps_cli;
-    int off_be, off_wd, off_bd, off_ws, off_bs, off_epsp, off_eps, P;
-    int32_t* step_dev;
-    unsigned long long* stamps;        // diagnostic builds only (-DVAEK_STAMPS): [block][wave][8] s_memtime
-};
-bool fused_mfma_supported(const vaek_ctx* c);
-int fused_mfma_launch(const vaek_ctx* c, const float* params, const void* fused_args, int grid, hipStream_t st);
+#ifdef __HIPCC__
+// flax.optim.Adam.apply_gradient (networks.py:100) for one parameter; (1 - beta) formed in double, as the oracle does
+__device__ __forceinline__ void adam_apply_f(float& p, float g, float& m, float& v, float lr, float bc1, float bc2) {
+    m = kAdamB1 * m + (float)(1.0 - 0.9) * g;
+    v = kAdamB2 * v + (float)(1.0 - 0.999) * g * g;
+    p = p - lr * (m / bc1) / (sqrtf(v / bc2) + kAdamEps);
+}
+#endif
 
-// ---- rng.hip ------------------------------------------------------------------------------
+// ---- fused_small.hip / fused_mfma.hip: arguments of the fused linear-VAE kernels ----------------
 struct BatchArgs {
     int kind;                   // 0 linear_gaussian, 1 sigmoid, 2 sphere
     const float* A;             // linear: [dd][did] row-major; sigmoid: [dd]; sphere: unused
@@ -206,6 +202,27 @@ struct BatchArgs {
     unsigned long long seed; const int32_t* step_dev; unsigned step_host, tag;
     int32_t* counter; int which; // make_batch_next: step = counter[which]; the launch stores counter[which ^ 1] = step + 1
 };
+
+struct FusedArgs {
+    const float* x; const float* z1; const float* z2;
+    float* partials; int pstride;      // [grid][pstride]
+    int B, D, L, ntiles;
+    float inv_bt, eps_cli;
+    int off_be, off_wd, off_bd, off_ws, off_bs, off_epsp, off_eps, P;
+    int32_t* step_dev;
+    unsigned long long* stamps;        // diagnostic builds only (-DVAEK_STAMPS): [block][wave][8] s_memtime
+    // single-launch step (fused_mfma.hip): the batch fits ONE workgroup, so there is nothing to reduce across workgroups
+    // and workgroup 0 finalizes itself -- closed-form terms, loss, Adam, step counter; workgroups 1.. (if any) draw the
+    // next batch (vaek_train_step_gen): the reference's loop body at its own batch size is one launch
+    int single;
+    float* grads; float* params_rw; float* m; float* v; float lr, rows_over_bt, rows;
+    float* loss_hist; long long loss_hist_cap;
+    int has_gen; BatchArgs gen;
+};
+bool fused_mfma_supported(const vaek_ctx* c);
+int fused_mfma_launch(const vaek_ctx* c, const float* params, const void* fused_args, int grid, hipStream_t st);
+
+// ---- rng.hip ------------------------------------------------------------------------------
 // validates the arguments of vaek_make_batch* and fills `out`
 int make_batch_args(vaek_ctx* ctx, int32_t kind, const float* A, int32_t dd, int32_t did, int32_t pad, float var_added,
                     float* x, float* z1, float* z2, int32_t rows, int64_t row0, uint64_t seed, const int32_t* step_dev,
