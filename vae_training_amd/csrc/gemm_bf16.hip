@@ -173,6 +173,23 @@ __global__ __launch_bounds__(HNT) void gemm_bf16_kernel(const HGemmArgs g) {
     }
     float* C = g.C;
     if (EPI == HEPI_DW) C += (long long)bz * g.slab_stride;
+    // epilogue inputs (relu mask source / z1) into registers before the first store: see gemm_f32.hip
+    constexpr bool kAux = EPI == HEPI_REPARAM || EPI == HEPI_DX;
+    float auxv[kAux ? 2 : 1][kAux ? 2 : 1][16];
+    if (kAux && (EPI != HEPI_DX || g.relu)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const bool in = col < g.N && row < g.M;
+                    auxv[kAux ? i : 0][kAux ? j : 0][r] = g.aux[in ? (long long)row * g.ldc + col : 0];
+                }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + (lane & 31);
@@ -188,6 +205,7 @@ __global__ __launch_bounds__(HNT) void gemm_bf16_kernel(const HGemmArgs g) {
                 if (row >= g.M) continue;
                 const long long o = (long long)row * g.ldc + col;
                 float v = acc[i][j][r];
+                const float ax = auxv[kAux ? i : 0][kAux ? j : 0][r];
                 if (EPI == HEPI_FWD) {
                     v += bias;
                     if (g.relu) v = fmaxf(v, 0.f);
@@ -195,9 +213,9 @@ __global__ __launch_bounds__(HNT) void gemm_bf16_kernel(const HGemmArgs g) {
                 } else if (EPI == HEPI_REPARAM) {
                     v += bias;
                     C[o] = v;
-                    g.C2[o] = v + sdev * g.aux[o];
+                    g.C2[o] = v + sdev * ax;
                 } else if (EPI == HEPI_DX) {
-                    if (g.relu) v = g.aux[o] > 0.f ? v : 0.f;
+                    if (g.relu) v = ax > 0.f ? v : 0.f;
                     if (g.accumulate) v += C[o];
                     C[o] = v;
                 } else {

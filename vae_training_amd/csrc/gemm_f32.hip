@@ -189,6 +189,28 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
         const float eps = g.eps_param ? g.eps_param[0] * g.eps_cli : g.eps_cli;
         e_inv_var = expf(-eps); e_sigma = expf(0.5f * eps); e_dscale = e_inv_var * g.inv_bt;
     }
+    // The epilogue's own inputs (relu mask source / z1 / x and z2) are gathered into registers BEFORE the first store:
+    // C and aux are plain pointers, so every load after a store to C has to wait behind it (they may alias as far as the
+    // compiler knows) and the epilogue became a chain of exposed load latencies -- dX ran 25 % slower than the forward
+    // GEMM of the same shape.
+    constexpr bool kAux = EPI == EPI_REPARAM || EPI == EPI_DX || EPI == EPI_ELBO;
+    float auxv[kAux ? TM : 1][kAux ? TN : 1][16], aux2v[EPI == EPI_ELBO ? TM : 1][EPI == EPI_ELBO ? TN : 1][16];
+    if (kAux && (EPI != EPI_DX || g.relu)) {
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            const int col = n0 + (wn * TN + jn) * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const bool in = col < g.N && row < g.M;
+                    const long long o = in ? (long long)row * g.ldc + col : 0;
+                    auxv[kAux ? i : 0][kAux ? jn : 0][r] = g.aux[o];
+                    if (EPI == EPI_ELBO) aux2v[EPI == EPI_ELBO ? i : 0][EPI == EPI_ELBO ? jn : 0][r] = g.aux2[o];
+                }
+        }
+    }
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
         const int col = n0 + (wn * TN + jn) * 32 + (lane & 31);
@@ -206,6 +228,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
                 if (row >= g.M) continue;
                 const long long o = (long long)row * g.ldc + col;
                 float v = acc[i][jn][r];
+                const float ax = auxv[kAux ? i : 0][kAux ? jn : 0][r];
                 if (EPI == EPI_FWD) {
                     v += bias;
                     if (g.relu) v = fmaxf(v, 0.f);
@@ -213,14 +236,14 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
                 } else if (EPI == EPI_REPARAM) {
                     v += bias;
                     C[o] = v;
-                    g.C2[o] = v + sdev * g.aux[o];
+                    g.C2[o] = v + sdev * ax;
                 } else if (EPI == EPI_DX) {
-                    if (g.relu) v = g.aux[o] > 0.f ? v : 0.f;
+                    if (g.relu) v = ax > 0.f ? v : 0.f;
                     if (g.accumulate) v += C[o];
                     C[o] = v;
                 } else if (EPI == EPI_ELBO) {
-                    const float z = g.aux2[o];
-                    const float rr = (v + bias) + e_sigma * z - g.aux[o];        // x_hat - x, x_hat = y + z2 e^{eps/2}
+                    const float z = aux2v[EPI == EPI_ELBO ? i : 0][EPI == EPI_ELBO ? jn : 0][r];
+                    const float rr = (v + bias) + e_sigma * z - ax;              // x_hat - x, x_hat = y + z2 e^{eps/2}
                     const float q = rr * rr * e_inv_var;
                     e_mse += 0.5f * q;
                     e_deps += -0.5f * q + 0.5f * e_sigma * z * rr * e_inv_var;
