@@ -185,8 +185,8 @@ def cpu_baseline(w, B, seconds):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--workload", default="M", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (weak) / global batch (strong); 0 = workload default")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
@@ -311,21 +311,22 @@ def main():
     # ---- roofline leg: the same K steps again with every library launch bracketed by hipEvents ----
     roofline = None
     if not args.no_roofline:
-        eng.profile_begin(max_records=args.steps * 64)
-        for i in range(args.steps):
+        rsteps = min(args.steps, 200)                       # kernel-timestamp leg: 200 steps are plenty (one event pair per launch)
+        eng.profile_begin(max_records=rsteps * 64)
+        for i in range(rsteps):
             one_step(i)
         torch.cuda.synchronize()
         rep = eng.profile_report()
         if rep:
             dom = max(rep, key=lambda k: rep[k]["total_ms"])
             avg_s = rep[dom]["total_ms"] / rep[dom]["count"] * 1e-3
-            per_step = rep[dom]["count"] / args.steps            # launches of the dominant kernel per step
+            per_step = rep[dom]["count"] / rsteps            # launches of the dominant kernel per step
             P = eng.P
             if flops_per_sample(w) / (4.0 * (2 * D + L)) > 300.0:   # above the f32/bf16 ridge: MFMA-bound (C3)
                 # layer-by-layer path: the Dense kernels run once per layer; price the step's flops against the
                 # time of all Dense launches of a step (kernel_avg_us stays the dominant kernel's own average)
                 alg = B_local * flops_per_sample(w)
-                gemm_s = sum(r["total_ms"] for k, r in rep.items() if k.startswith("gemm")) / args.steps * 1e-3
+                gemm_s = sum(r["total_ms"] for k, r in rep.items() if k.startswith("gemm")) / rsteps * 1e-3
                 peak, unit, bound = (2500.0 if args.dtype == "bf16" else 157.3), "TFLOP/s", "mfma"
                 achieved = alg / gemm_s / 1e12
             else:
@@ -338,9 +339,9 @@ def main():
                 traffic = json.load(open(tfile))["kernels"].get(dom, {}).get("traffic_bytes")
             roofline = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
                         "traffic": traffic, "kernel": dom, "kernel_avg_us": avg_s * 1e6,
-                        "launches_per_step": rep[dom]["count"] / args.steps,
+                        "launches_per_step": rep[dom]["count"] / rsteps,
                         "algorithmic_per_launch": alg,
-                        "step_kernels_us": {k: r["total_ms"] / args.steps * 1e3 for k, r in rep.items()},
+                        "step_kernels_us": {k: r["total_ms"] / rsteps * 1e3 for k, r in rep.items()},
                         "param_bytes_per_step": 32 * P}
             if rank == 0:       # the same denominators re-measured on THIS box by the library's micro-benchmarks
                 roofline["peak_measured"] = eng.measure_peaks()
