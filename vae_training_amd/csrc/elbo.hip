@@ -311,12 +311,6 @@ __global__ __launch_bounds__(256) void bulk_finalize_kernel(const FinalizeArgs a
     const bool vec = i0 + 3 < hi && slabs_of(i0 + 3) == S0 && a.slab_stride % 4 == 0 &&
                      (((uintptr_t)a.slabs | (uintptr_t)a.grads | (uintptr_t)a.params_rw | (uintptr_t)a.m | (uintptr_t)a.v) & 15) == 0;
     if (vec) {
-        // Adam state first: behind the store to grads these loads would have to wait for it (possible alias)
-        float4 p = make_float4(0.f, 0.f, 0.f, 0.f), m = p, v = p;
-        if (a.params_rw) {
-            p = *reinterpret_cast<const float4*>(a.params_rw + i0); m = *reinterpret_cast<const float4*>(a.m + i0);
-            v = *reinterpret_cast<const float4*>(a.v + i0);
-        }
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int s0 = 0; s0 < S0; s0 += 8) {           // 8 independent 16-byte loads in flight, summed in slab order
             float4 t[8];
@@ -329,6 +323,8 @@ __global__ __launch_bounds__(256) void bulk_finalize_kernel(const FinalizeArgs a
         }
         *reinterpret_cast<float4*>(a.grads + i0) = g;
         if (a.params_rw) {
+            float4 p = *reinterpret_cast<const float4*>(a.params_rw + i0), m = *reinterpret_cast<const float4*>(a.m + i0),
+                   v = *reinterpret_cast<const float4*>(a.v + i0);
             adam_apply(p.x, g.x, m.x, v.x, a.lr, bc1, bc2); adam_apply(p.y, g.y, m.y, v.y, a.lr, bc1, bc2);
             adam_apply(p.z, g.z, m.z, v.z, a.lr, bc1, bc2); adam_apply(p.w, g.w, m.w, v.w, a.lr, bc1, bc2);
             *reinterpret_cast<float4*>(a.params_rw + i0) = p; *reinterpret_cast<float4*>(a.m + i0) = m;
