@@ -383,8 +383,8 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
         fresh = {"samples_per_s": B_local * nrep * gsteps / dt, "us_per_step": dt / (nrep * gsteps) * 1e6,
-                 "note": "inputs drawn on the device each step (Philox work items in the finalize launch of the step before: "
-                         "vaek_train_step_gen) instead of pre-resident batches"}
+                 "note": "inputs drawn on the device each step by vaek_train_step_gen (Philox work items riding in the launches of "
+                         "the step before) instead of pre-resident batches"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
