@@ -24,7 +24,7 @@ for B in (100, 65536):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"B={B:6d} drop-in python loop : {dt / n * 1e6:8.1f} us/step  {B * n / dt:14.0f} samples/s")
     for pipe in (False, True):
-        m = build(B); loop = GraphLoop(m, steps_per_graph=50, pipeline=pipe)
+        m = build(B); loop = GraphLoop(m, pipeline=pipe)
         loop.run(200); torch.cuda.synchronize(); t0 = time.perf_counter(); n = 20000
         loop.run(n); torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print(f"B={B:6d} hipGraph loop (K7 rng, pipeline={pipe!s:5}): {dt / n * 1e6:8.1f} us/step  {B * n / dt:14.0f} samples/s  "

@@ -21,7 +21,7 @@ import torch
 
 
 class GraphLoop:
-    def __init__(self, vae_model, steps_per_graph=50, seed=None, loss_capacity=1 << 20, pipeline=True):
+    def __init__(self, vae_model, steps_per_graph=200, seed=None, loss_capacity=1 << 20, pipeline=True):
         m = vae_model
         self.m = m
         ds = m.dataset
