@@ -131,7 +131,10 @@ int vaek_adam_step(vaek_ctx* ctx, float* params, const float* grads, float* m, f
 /* VAE.train_step, networks.py:87-101, in place: reads params, x[B,D], z1[B,L], z2[B,D];
  * writes grads (vaek_grad_len floats; summed over ranks when the communicator is initialised),
  * updates params/m/v, increments *step_dev (device int32 Adam step counter), leaves the loss
- * in grads[P] (device; the reference keeps it un-synced too, vae.py:130). */
+ * in grads[P] (device; the reference keeps it un-synced too, vae.py:130).
+ * Launches: linear VAEs with D, L <= 32 (the metric) run two kernels -- forward/backward/partial sums, then
+ * reduction + Adam -- or ONE when the batch fits a workgroup (<= 256 rows, single GPU); any other MLP runs layer by
+ * layer.  Asynchronous on `stream`, capturable into a hipGraph (no host-side state per step). */
 int vaek_train_step(vaek_ctx* ctx, float* params, float* grads, float* m, float* v, int32_t* step_dev,
                     const float* x, const float* z1, const float* z2, float lr,
                     void* workspace, void* stream);
