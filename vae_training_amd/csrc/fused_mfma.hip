@@ -226,6 +226,32 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
 
     // inputs AFTER the weights: loads return in order, and the first product needs the weights and x only
     load_inputs(blockIdx.x);
+    // Where each of this thread's outputs (flat-gradient index t, t + 256, ...) will sit in the cross-wave reduction image
+    // of the epilogue -- worked out NOW, under the input loads' latency, instead of as ~40 VALU + divergent branches per
+    // output on the kernel's tail.  0xffff = an output this kernel leaves zero.
+    constexpr int PMAX = DP * LP + LP + (SIG ? 2 : 1) * (LP * DP + DP) + LP + 1 + kExtra;
+    constexpr int NOUT = (PMAX + 255) / 256;
+    unsigned short src_off[NOUT];
+    {
+        auto blk_off = [&](int gemm, int i, int jj) {
+            const int blk = gemm == 1 ? (i >> 4) * G::JB1 + (jj >> 4) : G::IB1 * G::JB1 + (i >> 4) * G::JB2 + (jj >> 4);
+            return (blk * 16 + (i & 15)) * 16 + (jj & 15);
+        };
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) {
+            const int idx = t + 256 * k;
+            int o = 0xffff;
+            if (idx < off_be) o = blk_off(2, idx / L, idx % L);                                   // dWe = x^T dmu
+            else if (idx < off_wd) o = G::NBLK * 256 + G::NB1 + idx - off_be;                      // dbe = 1^T dmu
+            else if (idx < off_bd) { const int kk = idx - off_wd; o = blk_off(1, kk / D, kk % D); }   // dWd = samples^T dy
+            else if (idx < off_bd + D) o = G::NBLK * 256 + idx - off_bd;                           // dbd = 1^T dy
+            else if (SIG && idx < off_bs) { const int kk = idx - off_ws; o = blk_off(1, kk / D, DP + kk % D); }
+            else if (SIG && idx < off_bs + D) o = G::NBLK * 256 + DP + idx - off_bs;
+            else if (idx >= off_epsp && idx < off_epsp + L) o = G::NBLK * 256 + G::NB1 + LP + idx - off_epsp;   // sum g*z1
+            else if (idx >= a.P && idx < a.P + 3) o = G::NBLK * 256 + G::NCS + idx - a.P;
+            src_off[k] = (unsigned short)o;
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);        // nothing that WAITS for a parameter may be scheduled above the input loads
 
 #pragma unroll
@@ -522,34 +548,28 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
         if (lane == 0) { CS[G::NCS + 0] = m0; CS[G::NCS + 1] = m1; CS[G::NCS + 2] = m2; }
     }
     __syncthreads();
-    auto fetch = [&](int gemm, int i, int jj) -> float {
-        const int blk = gemm == 1 ? (i >> 4) * G::JB1 + (jj >> 4) : G::IB1 * G::JB1 + (i >> 4) * G::JB2 + (jj >> 4);
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < G::NW; ++w) v += T[w * G::R_PER_WAVE + (blk * 16 + (i & 15)) * 16 + (jj & 15)];
-        return v;
-    };
     auto fetch_cs = [&](int k) -> float {
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < G::NW; ++w) v += T[w * G::R_PER_WAVE + G::NBLK * 256 + k];
         return v;
     };
-    auto batch_sum = [&](int idx) -> float {            // output idx of the flat gradient, summed over this workgroup's samples
+    auto batch_sum_k = [&](int k) -> float {            // this thread's k-th output, summed over the workgroup's four waves
+        const int o = src_off[k];
         float v = 0.f;
-        if (idx < off_be) v = fetch(2, idx / L, idx % L);                              // dWe = x^T dmu
-        else if (idx < off_wd) v = fetch_cs(G::NB1 + idx - off_be);                    // dbe = 1^T dmu
-        else if (idx < off_bd) { const int k = idx - off_wd; v = fetch(1, k / D, k % D); }   // dWd = samples^T dy
-        else if (idx < off_bd + D) v = fetch_cs(idx - off_bd);                         // dbd = 1^T dy
-        else if (SIG && idx < off_bs) { const int k = idx - off_ws; v = fetch(1, k / D, DP + k % D); }
-        else if (SIG && idx < off_bs + D) v = fetch_cs(DP + idx - off_bs);
-        else if (idx >= off_epsp && idx < off_epsp + L) v = fetch_cs(G::NB1 + LP + idx - off_epsp);   // sum g*z1
-        else if (idx >= a.P && idx < a.P + 3) v = fetch_cs(G::NCS + idx - a.P);
+        if (o != 0xffff) {
+#pragma unroll
+            for (int w = 0; w < G::NW; ++w) v += T[w * G::R_PER_WAVE + o];
+        }
         return v;
     };
     if (!SINGLE) {
         float* out = a.partials + (long long)blockIdx.x * a.pstride;
-        for (int idx = t; idx < a.P + kExtra; idx += 256) out[idx] = batch_sum(idx);
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) {
+            const int idx = t + 256 * k;
+            if (idx < a.P + kExtra) out[idx] = batch_sum_k(k);
+        }
         VAEK_MSTAMP(6);
         if (blockIdx.x == 0 && t == 0 && a.step_dev) a.step_dev[0] += 1;
         return;
@@ -558,8 +578,6 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
     // fused_finalize_kernel does in a second launch for bigger batches happens here: closed-form KL / log-variance terms,
     // the three means, Adam, the step counter, the loss ring.  All reads of params come before the barrier, all writes
     // after it.  (The two forms are never mixed for one context: grid == 1 always takes this one.)
-    constexpr int PMAX = DP * LP + LP + (SIG ? 2 : 1) * (LP * DP + DP) + LP + 1 + kExtra;
-    constexpr int NOUT = (PMAX + 255) / 256;
     const int tstep = a.step_dev[0] + 1;
     const float s_mse_t = fetch_cs(G::NCS + 0), s_musq_t = fetch_cs(G::NCS + 1), s_deps_t = fetch_cs(G::NCS + 2);
     float gk[NOUT], pk[NOUT], mk[NOUT], vk[NOUT];
@@ -568,7 +586,7 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
         const int idx = t + 256 * k;
         gk[k] = 0.f; pk[k] = 0.f; mk[k] = 0.f; vk[k] = 0.f;
         if (idx >= a.P + kExtra) continue;
-        float gq_ = batch_sum(idx);
+        float gq_ = batch_sum_k(k);
         if (idx < a.P) { pk[k] = a.params_rw[idx]; mk[k] = a.m[idx]; vk[k] = a.v[idx]; }
         if (idx >= off_epsp && idx < off_epsp + L) {
             const float lv = pk[k];
