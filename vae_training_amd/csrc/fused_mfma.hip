@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
     // loads of a wave (24 parameter, 32 input) leave before the first wait.  Measured: 8.76 -> 8.64 us per launch only --
     // the load phase is bandwidth-, not latency-bound, and at 260 VGPRs hipcc still copies the z1 / z2 registers away early
     // enough that the first products wait for ~3/4 of the bytes.
-    auto load_inputs = [&](int tile) {
+    auto load_inputs = [&](int tile, int what = 3) {
         const float* px[NSUB]; const float* pz2[NSUB]; const float* pz1[NSUB];
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) {
@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
         }
         // Issue order = order of first use: x of all four sub-tiles (the mu products can start when a quarter of the
         // tile's bytes have landed), then z1 (reparameterisation), then z2 (residual) -- loads return in order.
+        if (what & 1)
 #pragma unroll
         for (int s = 0; s < NSUB; ++s)
 #pragma unroll
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
                     for (int r = 0; r < 4; ++r) xv[s][db][r] = r < AD::nreg(db) ? px[s][min(AD::feat(db, g, r), D - 1)] : 0.f;
                 }
             }
+        if (what & 2)
 #pragma unroll
         for (int s = 0; s < NSUB; ++s)
 #pragma unroll
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
                     for (int r = 0; r < 4; ++r) z1v[s][lb][r] = r < AL::nreg(lb) ? pz1[s][min(AL::feat(lb, g, r), L - 1)] : 0.f;
                 }
             }
+        if (what & 2)
 #pragma unroll
         for (int s = 0; s < NSUB; ++s)
 #pragma unroll
@@ -175,6 +178,9 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
         return;
     }
 #endif
+    load_inputs(blockIdx.x, 1);
+    __builtin_amdgcn_sched_barrier(0);
+
     // ---- weights as MFMA A operands (lane = output row ai, k group akg), zero outside [D, L] -------
     // row ai of a block <-> (g', r') = (ai >> 2, ai & 3)
     auto latrow = [&](int lb) { return AL::feat(lb, ai >> 2, ai & 3); };
@@ -224,8 +230,9 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
         }
     const float eps_raw = a.off_eps >= 0 ? params[a.off_eps] : 0.f;
 
-    // inputs AFTER the weights: loads return in order, and the first product needs the weights and x only
-    load_inputs(blockIdx.x);
+    // z1 / z2 AFTER the weights (loads return in order, and the first product needs the weights and x only); x went out
+    // before the ~150 VALU of parameter indexing
+    load_inputs(blockIdx.x, 2);
     // Where each of this thread's outputs (flat-gradient index t, t + 256, ...) will sit in the cross-wave reduction image
     // of the epilogue -- worked out NOW, under the input loads' latency, instead of as ~40 VALU + divergent branches per
     // output on the kernel's tail.  0xffff = an output this kernel leaves zero.
