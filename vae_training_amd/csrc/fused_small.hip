@@ -406,33 +406,51 @@ constexpr int FIN_Q = 16;
 __device__ __forceinline__ void fused_finalize_block(const FusedFinArgs& a) {
     __shared__ float part[FIN_Q][64];
     __shared__ float sums[64];
-    const int n = a.P + kExtra;
+    __shared__ float klt[64];
+    // every kernel argument the block uses, read once, up front (hipcc otherwise re-reads them from the kernarg segment
+    // inside each branch, one scalar round trip at a time)
+    const int P = a.P, G = a.G, L = a.L, D = a.D, pstride = a.pstride, off_epsp = a.off_epsp, off_eps = a.off_eps;
+    const float eps_cli = a.eps_cli, rows_over_bt = a.rows_over_bt, inv_bt = a.inv_bt, rows = a.rows, lr = a.lr;
+    const float* const partials = a.partials; const float* const params = a.params;
+    float* const grads = a.grads; float* const params_rw = a.params_rw; float* const mp = a.m; float* const vp = a.v;
+    const int32_t* const step_dev = a.step_dev;
+    const int n = P + kExtra;
     const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int idx = n - 64 * ((int)blockIdx.x + 1) + o;
-    // Adam state of this output is fetched NOW, under the partial-row loads, not after the reduction
-    const bool adam = a.params_rw != nullptr && q == 0 && idx >= 0 && idx < a.P;
-    float p_old = 0.f, m_old = 0.f, v_old = 0.f;
-    int tstep = 0;
-    if (adam) { p_old = a.params_rw[idx]; m_old = a.m[idx]; v_old = a.v[idx]; tstep = a.step_dev[0]; }
-    // closed-form KL pieces: each epsilon_p lane contributes its own 1 + lv - e^lv (block 0 holds them all)
-    __shared__ float klt[64];
-    const bool is_lv = q == 0 && idx >= a.off_epsp && idx < a.off_epsp + a.L;
-    const float lv_own = is_lv ? a.params[idx] : 0.f;
-    const float eps_par = (q == 0 && blockIdx.x == 0 && a.off_eps >= 0) ? a.params[a.off_eps] : 0.f;
+    // ---- ALL global loads first, UNCONDITIONAL (clamped indices, dummy sources for absent arrays), selects afterwards.
+    // With `cond ? ptr[i] : 0` hipcc loads inside a branch and merges the value there -- an s_waitcnt per load site: this
+    // kernel was four dependent memory round trips (Adam state, logvar_e, epsilon, then the partial rows) where one does.
+    const int idc = idx > 0 ? idx : 0;                       // outputs below 0 do not exist (first block's low lanes)
+    const int ipc = idc < P ? idc : P - 1;                    // parameter index for lanes that own a parameter
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int gq = q + u * FIN_Q;
+        v[u] = partials[(long long)(gq < G ? gq : G - 1) * pstride + idc];
+    }
+    const float* const ps = params_rw ? params_rw : params;          // same memory; m / v absent in grads-only mode
+    const float p_ld = ps[ipc], m_ld = (mp ? mp : params)[ipc], v_ld = (vp ? vp : params)[ipc];
+    const int tstep = step_dev ? step_dev[0] : 0;             // uniform: a scalar load
+    const float eps_ld = params[off_eps > 0 ? off_eps : 0];
+    // ---- from here on: arithmetic on registers
+    const bool adam = params_rw != nullptr && q == 0 && idx >= 0 && idx < P;
+    float p_old = p_ld, m_old = m_ld, v_old = v_ld;
+    const bool is_lv = q == 0 && idx >= off_epsp && idx < off_epsp + L;
+    const float lv_own = is_lv ? p_ld : 0.f;
+    const float eps_par = off_eps >= 0 ? eps_ld : 0.f;
     if (q == 0) klt[o] = is_lv ? 1.f + lv_own - expf(lv_own) : 0.f;
     float acc = 0.f;
-    if (idx >= 0) {
-        const float* p = a.partials + idx;
-        for (int g0 = q; g0 < a.G; g0 += FIN_Q * 16) {
-            float v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int g = g0 + u * FIN_Q;
-                v[u] = g < a.G ? p[(long long)g * a.pstride] : 0.f;
-            }
+    for (int u = 0; u < 16; ++u) acc += (idx >= 0 && q + u * FIN_Q < G) ? v[u] : 0.f;
+    for (int g0 = q + FIN_Q * 16; g0 < G; g0 += FIN_Q * 16) {            // more than 256 partial rows: further batches
+        float w[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) acc += v[u];
+        for (int u = 0; u < 16; ++u) {
+            const int gq = g0 + u * FIN_Q;
+            w[u] = partials[(long long)(gq < G ? gq : G - 1) * pstride + idc];
         }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += (idx >= 0 && g0 + u * FIN_Q < G) ? w[u] : 0.f;
     }
     part[q][o] = acc;
     __syncthreads();
@@ -447,33 +465,33 @@ __device__ __forceinline__ void fused_finalize_block(const FusedFinArgs& a) {
     float g = live ? sums[o] : 0.f;
     const int base = n - 64 * ((int)blockIdx.x + 1);          // index of sums[0]
     if (!live) {
-    } else if (idx >= a.off_epsp && idx < a.off_epsp + a.L) {
+    } else if (idx >= off_epsp && idx < off_epsp + L) {
         const float lv = lv_own;
-        g = 0.5f * expf(0.5f * lv) * g - 0.5f * (1.f - expf(lv)) * a.rows_over_bt;
-    } else if (idx == a.off_eps) {
-        g = a.eps_cli * (sums[a.P + 2 - base] + 0.5f * a.rows * (float)a.D) * a.inv_bt;
-    } else if (idx >= a.P) {
-        if (idx < a.P + 3) {
+        g = 0.5f * expf(0.5f * lv) * g - 0.5f * (1.f - expf(lv)) * rows_over_bt;
+    } else if (idx == off_eps) {
+        g = eps_cli * (sums[P + 2 - base] + 0.5f * rows * (float)D) * inv_bt;
+    } else if (idx >= P) {
+        if (idx < P + 3) {
             float klc = 0.f;
-            for (int l = 0; l < a.L; ++l) klc += klt[a.off_epsp - base + l];
-            const float eps = a.off_eps >= 0 ? eps_par * a.eps_cli : a.eps_cli;
-            const float dkl = (0.5f * sums[a.P + 1 - base] - 0.5f * a.rows * klc) * a.inv_bt;
-            const float mse = (sums[a.P - base] + 0.5f * a.rows * (float)a.D * (kLog2Pi + eps)) * a.inv_bt;
-            g = idx == a.P ? dkl + mse : (idx == a.P + 1 ? dkl : mse);
+            for (int l = 0; l < L; ++l) klc += klt[off_epsp - base + l];
+            const float eps = off_eps >= 0 ? eps_par * eps_cli : eps_cli;
+            const float dkl = (0.5f * sums[P + 1 - base] - 0.5f * rows * klc) * inv_bt;
+            const float mse = (sums[P - base] + 0.5f * rows * (float)D * (kLog2Pi + eps)) * inv_bt;
+            g = idx == P ? dkl + mse : (idx == P + 1 ? dkl : mse);
         } else {
             g = 0.f;
         }
     }
     __syncthreads();            // every read of params above precedes every Adam write below
     if (!live) return;
-    if (a.comm.world > 1) g = comm_exchange_sum(a.comm, (unsigned)a.step_dev[0], idx, g);   // xGMI, all ranks
-    a.grads[idx] = g;
-    if (idx == a.P && a.loss_hist) a.loss_hist[(long long)(a.step_dev[0] - 1) % a.loss_hist_cap] = g;
+    if (a.comm.world > 1) g = comm_exchange_sum(a.comm, (unsigned)tstep, idx, g);   // xGMI, all ranks
+    grads[idx] = g;
+    if (idx == P && a.loss_hist) a.loss_hist[(long long)(tstep - 1) % a.loss_hist_cap] = g;
     if (adam) {
         const float bc1 = -expm1f((float)tstep * -0.10536051565782628f);
         const float bc2 = -expm1f((float)tstep * -0.0010005003335835335f);
-        adam_apply_f(p_old, g, m_old, v_old, a.lr, bc1, bc2);
-        a.params_rw[idx] = p_old; a.m[idx] = m_old; a.v[idx] = v_old;
+        adam_apply_f(p_old, g, m_old, v_old, lr, bc1, bc2);
+        params_rw[idx] = p_old; mp[idx] = m_old; vp[idx] = v_old;
     }
 }
 
