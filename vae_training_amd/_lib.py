@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvaek.so")
+LIB_PATH = os.environ.get("VAEK_LIB_PATH") or os.path.join(_HERE, "csrc", "libvaek.so")      # override: A/B builds, diagnostics
 VAEK_MAX_HIDDEN = 8
 VAEK_F32, VAEK_BF16 = 0, 1
 VAEK_ACT_NONE, VAEK_ACT_RELU = 0, 1
