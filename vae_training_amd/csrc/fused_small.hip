@@ -406,7 +406,6 @@ constexpr int FIN_Q = 16;
 __device__ __forceinline__ void fused_finalize_block(const FusedFinArgs& a) {
     __shared__ float part[FIN_Q][64];
     __shared__ float sums[64];
-    __shared__ float klt[64];
     // every kernel argument the block uses, read once, up front (hipcc otherwise re-reads them from the kernarg segment
     // inside each branch, one scalar round trip at a time)
     const int P = a.P, G = a.G, L = a.L, D = a.D, pstride = a.pstride, off_epsp = a.off_epsp, off_eps = a.off_eps;
@@ -438,7 +437,14 @@ __device__ __forceinline__ void fused_finalize_block(const FusedFinArgs& a) {
     const bool is_lv = q == 0 && idx >= off_epsp && idx < off_epsp + L;
     const float lv_own = is_lv ? p_ld : 0.f;
     const float eps_par = off_eps >= 0 ? eps_ld : 0.f;
-    if (q == 0) klt[o] = is_lv ? 1.f + lv_own - expf(lv_own) : 0.f;
+    // closed-form KL constant sum_l (1 + lv - e^lv): every epsilon_p lane sits in wave 0 of block 0 (tail-aligned blocks), so
+    // one wave reduction gives it to the loss lanes -- under the first barrier, instead of a chain of L dependent LDS reads
+    // everything that depends only on the loaded state is worked out HERE, under the partial rows' latency, not on the tail
+    // behind the reduction: e^lv, e^{lv/2}, the KL constant, Adam's bias corrections
+    const float e_lv = expf(lv_own), e_hlv = expf(0.5f * lv_own);
+    const float klc_w = q == 0 ? wsum(is_lv ? 1.f + lv_own - e_lv : 0.f) : 0.f;
+    const float bc1 = -expm1f((float)tstep * -0.10536051565782628f);
+    const float bc2 = -expm1f((float)tstep * -0.0010005003335835335f);
     float acc = 0.f;
 #pragma unroll
     for (int u = 0; u < 16; ++u) acc += (idx >= 0 && q + u * FIN_Q < G) ? v[u] : 0.f;
@@ -466,14 +472,12 @@ __device__ __forceinline__ void fused_finalize_block(const FusedFinArgs& a) {
     const int base = n - 64 * ((int)blockIdx.x + 1);          // index of sums[0]
     if (!live) {
     } else if (idx >= off_epsp && idx < off_epsp + L) {
-        const float lv = lv_own;
-        g = 0.5f * expf(0.5f * lv) * g - 0.5f * (1.f - expf(lv)) * rows_over_bt;
+        g = 0.5f * e_hlv * g - 0.5f * (1.f - e_lv) * rows_over_bt;
     } else if (idx == off_eps) {
         g = eps_cli * (sums[P + 2 - base] + 0.5f * rows * (float)D) * inv_bt;
     } else if (idx >= P) {
         if (idx < P + 3) {
-            float klc = 0.f;
-            for (int l = 0; l < L; ++l) klc += klt[off_epsp - base + l];
+            const float klc = klc_w;
             const float eps = off_eps >= 0 ? eps_par * eps_cli : eps_cli;
             const float dkl = (0.5f * sums[P + 1 - base] - 0.5f * rows * klc) * inv_bt;
             const float mse = (sums[P - base] + 0.5f * rows * (float)D * (kLog2Pi + eps)) * inv_bt;
@@ -482,14 +486,13 @@ __device__ __forceinline__ void fused_finalize_block(const FusedFinArgs& a) {
             g = 0.f;
         }
     }
-    __syncthreads();            // every read of params above precedes every Adam write below
+    // (no barrier needed here for "params read before written": every global load of this block was issued at the top and
+    // has landed -- __syncthreads drains vmcnt -- before the first barrier; nothing below reads global memory)
     if (!live) return;
     if (a.comm.world > 1) g = comm_exchange_sum(a.comm, (unsigned)tstep, idx, g);   // xGMI, all ranks
     grads[idx] = g;
     if (idx == P && a.loss_hist) a.loss_hist[(long long)(tstep - 1) % a.loss_hist_cap] = g;
     if (adam) {
-        const float bc1 = -expm1f((float)tstep * -0.10536051565782628f);
-        const float bc2 = -expm1f((float)tstep * -0.0010005003335835335f);
         adam_apply_f(p_old, g, m_old, v_old, lr, bc1, bc2);
         params_rw[idx] = p_old; mp[idx] = m_old; vp[idx] = v_old;
     }
