@@ -563,19 +563,21 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
     };
     auto batch_sum_k = [&](int k) -> float {            // this thread's k-th output, summed over the workgroup's four waves
         const int o = src_off[k];
+        const int oc = o != 0xffff ? o : 0;               // unconditional LDS reads, select afterwards
         float v = 0.f;
-        if (o != 0xffff) {
 #pragma unroll
-            for (int w = 0; w < G::NW; ++w) v += T[w * G::R_PER_WAVE + o];
-        }
-        return v;
+        for (int w = 0; w < G::NW; ++w) v += T[w * G::R_PER_WAVE + oc];
+        return o != 0xffff ? v : 0.f;
     };
     if (!SINGLE) {
         float* out = a.partials + (long long)blockIdx.x * a.pstride;
+        float ov[NOUT];
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) ov[k] = batch_sum_k(k);       // all reads in flight, then the stores
 #pragma unroll
         for (int k = 0; k < NOUT; ++k) {
             const int idx = t + 256 * k;
-            if (idx < a.P + kExtra) out[idx] = batch_sum_k(k);
+            if (idx < a.P + kExtra) out[idx] = ov[k];
         }
         VAEK_MSTAMP(6);
         if (blockIdx.x == 0 && t == 0 && a.step_dev) a.step_dev[0] += 1;
