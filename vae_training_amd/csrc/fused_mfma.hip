@@ -63,7 +63,12 @@ struct MGeom {
     static constexpr int TILE = 256, NW = 4, NSUB = 4;
     static constexpr int TS = TILE + 2;
     static constexpr int NB1 = DP * (SIG ? 2 : 1);
-    static constexpr int FS = 0, FX = FS + LP, FDY = FX + DP, FDM = FDY + NB1, NF = FDM + LP;
+    // A ROW OF ONES behind the samples rows / behind the x rows of the operand image, where the last 16-row block of that
+    // operand has a spare row anyway (LP resp. DP not a multiple of 16): [samples | 1]^T dy and [x | 1]^T dmu then deliver
+    // the bias gradients as one more output row of MFMAs that run regardless -- no per-sample column-sum adds in the
+    // chain, no DPP row reductions and LDS traffic for them on the tail.
+    static constexpr int ONE1 = LP % 16 != 0 ? 1 : 0, ONE2 = DP % 16 != 0 ? 1 : 0;
+    static constexpr int FS = 0, FX = FS + LP + ONE1, FDY = FX + DP + ONE2, FDM = FDY + NB1, NF = FDM + LP;
     static constexpr int IB1 = (LP + 15) / 16, JB1 = (NB1 + 15) / 16, IB2 = (DP + 15) / 16, JB2 = (LP + 15) / 16;
     static constexpr int NBLK = IB1 * JB1 + IB2 * JB2;
     static constexpr int NF_PAD = FDM + JB2 * 16;
@@ -233,6 +238,8 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
     // z1 / z2 AFTER the weights (loads return in order, and the first product needs the weights and x only); x went out
     // before the ~150 VALU of parameter indexing
     load_inputs(blockIdx.x, 2);
+    if (G::ONE1) T[(G::FS + LP) * G::TS + t] = 1.f;          // each wave reads back only its own 64 columns: no barrier needed
+    if (G::ONE2) T[(G::FX + DP) * G::TS + t] = 1.f;
     // Where each of this thread's outputs (flat-gradient index t, t + 256, ...) will sit in the cross-wave reduction image
     // of the epilogue -- worked out NOW, under the input loads' latency, instead of as ~40 VALU + divergent branches per
     // output on the kernel's tail.  0xffff = an output this kernel leaves zero.
@@ -249,11 +256,11 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
             const int idx = t + 256 * k;
             int o = 0xffff;
             if (idx < off_be) o = blk_off(2, idx / L, idx % L);                                   // dWe = x^T dmu
-            else if (idx < off_wd) o = G::NBLK * 256 + G::NB1 + idx - off_be;                      // dbe = 1^T dmu
+            else if (idx < off_wd) o = G::ONE2 ? blk_off(2, DP, idx - off_be) : G::NBLK * 256 + G::NB1 + idx - off_be;   // dbe = 1^T dmu
             else if (idx < off_bd) { const int kk = idx - off_wd; o = blk_off(1, kk / D, kk % D); }   // dWd = samples^T dy
-            else if (idx < off_bd + D) o = G::NBLK * 256 + idx - off_bd;                           // dbd = 1^T dy
+            else if (idx < off_bd + D) o = G::ONE1 ? blk_off(1, LP, idx - off_bd) : G::NBLK * 256 + idx - off_bd;        // dbd = 1^T dy
             else if (SIG && idx < off_bs) { const int kk = idx - off_ws; o = blk_off(1, kk / D, DP + kk % D); }
-            else if (SIG && idx < off_bs + D) o = G::NBLK * 256 + DP + idx - off_bs;
+            else if (SIG && idx < off_bs + D) o = G::ONE1 ? blk_off(1, LP, DP + idx - off_bs) : G::NBLK * 256 + DP + idx - off_bs;
             else if (idx >= off_epsp && idx < off_epsp + L) o = G::NBLK * 256 + G::NB1 + LP + idx - off_epsp;   // sum g*z1
             else if (idx >= a.P && idx < a.P + 3) o = G::NBLK * 256 + G::NCS + idx - a.P;
             src_off[k] = (unsigned short)o;
@@ -398,8 +405,8 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
                     s_deps += -0.5f * q + 0.5f * sigma * z2v[s][db][r] * rr * inv_var;
                     const float dyd = rr * dscale;
                     dyv[s][db][r] = dyd;
-                    cs_dy[db][r] += dyd;
-                    if (SIG) { const float ds = dyd * sg * (1.f - sg); dysv[s][db][r] = ds; cs_dys[db][r] += ds; }
+                    if (!G::ONE1) cs_dy[db][r] += dyd;
+                    if (SIG) { const float ds = dyd * sg * (1.f - sg); dysv[s][db][r] = ds; if (!G::ONE1) cs_dys[db][r] += ds; }
                 }
         VAEK_MSTAMP(3);
         // ---- g^T = Wd dy^T (+ Ws dys^T) ------------------------------------------------------------------
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
                     const int l = AL::feat(lb, g, r);
                     const float gl = gq[s][lb][r];
                     const float dmu = valid[s] ? fmaf(mu[s][lb][r], a.inv_bt, gl) : 0.f;     // dmu = g + mu/B
-                    cs_dmu[lb][r] += dmu;
+                    if (!G::ONE2) cs_dmu[lb][r] += dmu;
                     cs_gz[lb][r] = fmaf(gl, z1v[s][lb][r], cs_gz[lb][r]);                     // reparam part of d lv
                     if (l < LP) { Tc[(G::FS + l) * G::TS] = sv[s][lb][r]; Tc[(G::FDM + l) * G::TS] = dmu; }
                 }
@@ -536,18 +543,24 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
 #pragma unroll
             for (int r = 0; r < AD::nreg(db); ++r) {
                 const int d = AD::feat(db, g, r);
-                const float v = rowsum(cs_dy[db][r]);
-                float vs = 0.f;
-                if (SIG) vs = rowsum(cs_dys[db][r]);
-                if (j == 0 && d < DP) { CS[d] = v; if (SIG) CS[DP + d] = vs; }
+                if (!G::ONE1) {
+                    const float v = rowsum(cs_dy[db][r]);
+                    float vs = 0.f;
+                    if (SIG) vs = rowsum(cs_dys[db][r]);
+                    if (j == 0 && d < DP) { CS[d] = v; if (SIG) CS[DP + d] = vs; }
+                }
             }
 #pragma unroll
         for (int lb = 0; lb < NLB; ++lb)
 #pragma unroll
             for (int r = 0; r < AL::nreg(lb); ++r) {
                 const int l = AL::feat(lb, g, r);
-                const float v = rowsum(cs_dmu[lb][r]), w = rowsum(cs_gz[lb][r]);
-                if (j == 0 && l < LP) { CS[G::NB1 + l] = v; CS[G::NB1 + LP + l] = w; }
+                const float w = rowsum(cs_gz[lb][r]);
+                if (j == 0 && l < LP) CS[G::NB1 + LP + l] = w;
+                if (!G::ONE2) {
+                    const float v = rowsum(cs_dmu[lb][r]);
+                    if (j == 0 && l < LP) CS[G::NB1 + l] = v;
+                }
             }
         float m0 = rowsum(s_mse), m1 = rowsum(s_musq), m2 = rowsum(s_deps);      // 16 lanes by DPP, then the 4 rows
 #pragma unroll
