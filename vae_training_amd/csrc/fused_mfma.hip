@@ -563,9 +563,15 @@ __global__ __launch_bounds__(256) void fused_linear_mfma_kernel(const float* __r
                 }
             }
         float m0 = rowsum(s_mse), m1 = rowsum(s_musq), m2 = rowsum(s_deps);      // 16 lanes by DPP, then the 4 rows
-#pragma unroll
-        for (int o = 32; o >= 16; o >>= 1) { m0 += __shfl_xor(m0, o, 64); m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64); }
-        if (lane == 0) { CS[G::NCS + 0] = m0; CS[G::NCS + 1] = m1; CS[G::NCS + 2] = m2; }
+        // the four rows by two more DPP adds (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3: lane 63 ends
+        // up with the wave's total) -- __shfl_xor is two trips through the LDS crossbar per value
+        auto rows4 = [&](float v) {
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));
+            return v;
+        };
+        m0 = rows4(m0); m1 = rows4(m1); m2 = rows4(m2);
+        if (lane == 63) { CS[G::NCS + 0] = m0; CS[G::NCS + 1] = m1; CS[G::NCS + 2] = m2; }
     }
     __syncthreads();
     auto fetch_cs = [&](int k) -> float {
