@@ -405,7 +405,6 @@ struct FusedFinArgs {
 constexpr int FIN_Q = 16;
 __device__ __forceinline__ void fused_finalize_block(const FusedFinArgs& a) {
     __shared__ float part[FIN_Q][64];
-    __shared__ float sums[64];
     // every kernel argument the block uses, read once, up front (hipcc otherwise re-reads them from the kernarg segment
     // inside each branch, one scalar round trip at a time)
     const int P = a.P, G = a.G, L = a.L, D = a.D, pstride = a.pstride, off_epsp = a.off_epsp, off_eps = a.off_eps;
@@ -460,27 +459,27 @@ __device__ __forceinline__ void fused_finalize_block(const FusedFinArgs& a) {
     }
     part[q][o] = acc;
     __syncthreads();
-    if (q == 0) {
-        float sacc = 0.f;
+    if (q != 0) return;                // wave 0 finishes alone: nothing below needs another workgroup barrier
+    float sacc = 0.f;
 #pragma unroll
-        for (int u = 0; u < FIN_Q; ++u) sacc += part[u][o];
-        sums[o] = sacc;
-    }
-    __syncthreads();
-    const bool live = q == 0 && idx >= 0;
-    float g = live ? sums[o] : 0.f;
-    const int base = n - 64 * ((int)blockIdx.x + 1);          // index of sums[0]
+    for (int u = 0; u < FIN_Q; ++u) sacc += part[u][o];
+    const bool live = idx >= 0;
+    float g = live ? sacc : 0.f;
+    // block 0 covers outputs [n - 64, n): the three scalar sums sit in lanes 60, 61, 62 of this wave -- v_readlane, not LDS
+    const float s_mse = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sacc), 60));
+    const float s_musq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sacc), 61));
+    const float s_deps = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sacc), 62));
     if (!live) {
     } else if (idx >= off_epsp && idx < off_epsp + L) {
         g = 0.5f * e_hlv * g - 0.5f * (1.f - e_lv) * rows_over_bt;
     } else if (idx == off_eps) {
-        g = eps_cli * (sums[P + 2 - base] + 0.5f * rows * (float)D) * inv_bt;
+        g = eps_cli * (s_deps + 0.5f * rows * (float)D) * inv_bt;
     } else if (idx >= P) {
         if (idx < P + 3) {
             const float klc = klc_w;
             const float eps = off_eps >= 0 ? eps_par * eps_cli : eps_cli;
-            const float dkl = (0.5f * sums[P + 1 - base] - 0.5f * rows * klc) * inv_bt;
-            const float mse = (sums[P - base] + 0.5f * rows * (float)D * (kLog2Pi + eps)) * inv_bt;
+            const float dkl = (0.5f * s_musq - 0.5f * rows * klc) * inv_bt;
+            const float mse = (s_mse + 0.5f * rows * (float)D * (kLog2Pi + eps)) * inv_bt;
             g = idx == P ? dkl + mse : (idx == P + 1 ? dkl : mse);
         } else {
             g = 0.f;
