@@ -108,6 +108,27 @@ __device__ __forceinline__ void hstore_mncont(__bf16* s, const float (&v)[HKU][4
     }
 }
 
+// Full-tile forms (every load unconditional): see gemm_f32.hip -- a load under `if (mn < MN)` is waited for where it is issued.
+template <int HBK, int HKU = HBK / 8>
+__device__ __forceinline__ void hfetch_kcont_full(const float* __restrict__ p, int ld, int mn0, int k0, float (&v)[HKU][4]) {
+    constexpr int TPR = HBK / 4, RPP = HNT / TPR;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < HKU; ++u) {
+        const float4 f = *reinterpret_cast<const float4*>(p + (long long)(mn0 + t / TPR + RPP * u) * ld + k0 + (t % TPR) * 4);
+        v[u][0] = f.x; v[u][1] = f.y; v[u][2] = f.z; v[u][3] = f.w;
+    }
+}
+template <int HBK, int HKU = HBK / 8>
+__device__ __forceinline__ void hfetch_mncont_full(const float* __restrict__ p, int ld, int mn0, int k0, float (&v)[HKU][4]) {
+    const int t = threadIdx.x;
+    const float* q = p + (long long)(k0 + (HBK / 2) * (t >> 7)) * ld + mn0 + (t & 127);
+#pragma unroll
+    for (int u = 0; u < HKU; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[u][c] = q[(long long)(4 * u + c) * ld];
+}
+
 template <bool A_KCONT, bool B_KCONT, int EPI, int HBK>
 __global__ __launch_bounds__(HNT) void gemm_bf16_kernel(const HGemmArgs g) {
     constexpr int HSTR = HBK + 8, HKU = HBK / 8;
@@ -142,10 +163,15 @@ __global__ __launch_bounds__(HNT) void gemm_bf16_kernel(const HGemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float ra[HKU][4], rb[HKU][4];
+    const bool a_in = A_KCONT ? (a_vec && m0 + HBM_ <= g.M) : m0 + HBM_ <= g.a_mem;
+    const bool b_in = B_KCONT ? (b_vec && n0 + HBN_ <= g.N) : n0 + HBN_ <= g.N;
     auto fetch = [&](int k0) {
-        if (A_KCONT) hfetch_kcont<HBK>(g.A, g.lda, m0, g.M, k0, kend, a_vec, ra);
+        const bool k_in = k0 + HBK <= kend;                // uniform: a scalar branch
+        if (a_in && k_in) { if (A_KCONT) hfetch_kcont_full<HBK>(g.A, g.lda, m0, k0, ra); else hfetch_mncont_full<HBK>(g.A, g.lda, m0, k0, ra); }
+        else if (A_KCONT) hfetch_kcont<HBK>(g.A, g.lda, m0, g.M, k0, kend, a_vec, ra);
         else hfetch_mncont<HBK>(g.A, g.lda, m0, g.a_mem, EPI == HEPI_DW, k0, kend, a_vec, ra);
-        if (B_KCONT) hfetch_kcont<HBK>(g.B, g.ldb, n0, g.N, k0, kend, b_vec, rb);
+        if (b_in && k_in) { if (B_KCONT) hfetch_kcont_full<HBK>(g.B, g.ldb, n0, k0, rb); else hfetch_mncont_full<HBK>(g.B, g.ldb, n0, k0, rb); }
+        else if (B_KCONT) hfetch_kcont<HBK>(g.B, g.ldb, n0, g.N, k0, kend, b_vec, rb);
         else hfetch_mncont<HBK>(g.B, g.ldb, n0, g.N, false, k0, kend, b_vec, rb);
     };
     if (kbeg < kend) fetch(kbeg);

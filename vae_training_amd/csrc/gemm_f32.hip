@@ -115,6 +115,35 @@ __device__ __forceinline__ void store_mncont(float* s, const float (&v)[(T * BK 
     }
 }
 
+// Full-tile forms: every load unconditional.  The general forms above load under `if (mn < MN)` / `if (k + 3 < kend)`;
+// hipcc merges a conditionally loaded value into its zero-initialised registers INSIDE the branch, i.e. it waits for each
+// load where it is issued -- the "prefetch under the MFMAs" was a chain of exposed latencies.  A tile that lies fully
+// inside the operand (almost all of them) takes these.
+template <int T, int BK>
+__device__ __forceinline__ void fetch_kcont_full(const float* __restrict__ p, int ld, int mn0, int k0,
+                                                 float (&v)[(T * BK / 4 + NT - 1) / NT][4]) {
+    constexpr int NU = (T * BK / 4 + NT - 1) / NT;
+    static_assert(T * BK / 4 % NT == 0, "whole passes");
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const int u = threadIdx.x + i * NT;
+        const float4 f = *reinterpret_cast<const float4*>(p + (long long)(mn0 + u / (BK / 4)) * ld + k0 + (u % (BK / 4)) * 4);
+        v[i][0] = f.x; v[i][1] = f.y; v[i][2] = f.z; v[i][3] = f.w;
+    }
+}
+template <int T, int BK>
+__device__ __forceinline__ void fetch_mncont_full(const float* __restrict__ p, int ld, int mn0, int k0,
+                                                  float (&v)[(T * BK / 4 + NT - 1) / NT][4]) {
+    constexpr int NU = (T * BK / 4 + NT - 1) / NT;
+    static_assert(T * BK / 4 % NT == 0, "whole passes");
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const int u = threadIdx.x + i * NT;
+        const float4 f = *reinterpret_cast<const float4*>(p + (long long)(k0 + u / (T / 4)) * ld + mn0 + (u % (T / 4)) * 4);
+        v[i][0] = f.x; v[i][1] = f.y; v[i][2] = f.z; v[i][3] = f.w;
+    }
+}
+
 template <bool A_KCONT, bool B_KCONT, int EPI, int WM, int WN, int BK, int TM = 1, int TN = 1>
 __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, SA = BM + 4, SB = BN + 4;
@@ -154,10 +183,16 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
 
     float ra[(BM * BK / 4 + NT - 1) / NT][4], rb[(BN * BK / 4 + NT - 1) / NT][4];
+    // does this workgroup's tile lie fully inside each operand (rows / columns; the k range is checked per k-tile)?
+    const bool a_in = a_vec && (A_KCONT ? m0 + BM <= g.M : m0 + BM <= g.a_mem);
+    const bool b_in = b_vec && n0 + BN <= g.N;
     auto fetch = [&](int k0) {
-        if (A_KCONT) fetch_kcont<BM, BK>(g.A, g.lda, m0, g.M, k0, kend, a_vec, ra);
+        const bool k_in = k0 + BK <= kend;                 // uniform: a scalar branch
+        if (a_in && k_in) { if (A_KCONT) fetch_kcont_full<BM, BK>(g.A, g.lda, m0, k0, ra); else fetch_mncont_full<BM, BK>(g.A, g.lda, m0, k0, ra); }
+        else if (A_KCONT) fetch_kcont<BM, BK>(g.A, g.lda, m0, g.M, k0, kend, a_vec, ra);
         else fetch_mncont<BM, BK>(g.A, g.lda, m0, g.a_mem, EPI == EPI_DW, k0, kend, a_vec, ra);
-        if (B_KCONT) fetch_kcont<BN, BK>(g.B, g.ldb, n0, g.N, k0, kend, b_vec, rb);
+        if (b_in && k_in) { if (B_KCONT) fetch_kcont_full<BN, BK>(g.B, g.ldb, n0, k0, rb); else fetch_mncont_full<BN, BK>(g.B, g.ldb, n0, k0, rb); }
+        else if (B_KCONT) fetch_kcont<BN, BK>(g.B, g.ldb, n0, g.N, k0, kend, b_vec, rb);
         else fetch_mncont<BN, BK>(g.B, g.ldb, n0, g.N, false, k0, kend, b_vec, rb);
     };
     if (kbeg < kend) fetch(kbeg);
