@@ -331,13 +331,15 @@ static int launch(const GemmArgs& g, int splits, hipStream_t st) {
     // 1.75 -> 1.53 ms, dX 2.22 -> 1.93 ms, dW|db 2.23 -> 2.02 ms with the split count raised to match, api.hip).  Only
     // where the big tiles still give every CU two workgroups (C2, 8 192 rows: 128 tiles, is faster at 64 x 64) and
     // the reduction is long enough to matter (C4's 20 -> 4096 decoder is all epilogue: 148 us at 64 x 64, 186 at 128).
-    // Measured and dropped here: BK = 32 (3 waves per SIMD instead of 4: 5-8 % slower), a split count that makes the
+    // BK = 32 for this shape since the full-tile fetch made the prefetch asynchronous (C3 5.00 -> 4.91 ms; it was 5-8 %
+    // slower while the conditional loads serialised it; 64 x 64 stays at 16: C2 0.156 vs 0.163 ms).
+    // Measured and dropped here: a split count that makes the
     // workgroups a whole number per CU (2 per CU: 15 % slower than 2.4), the ones row of [X | 1]^T as a streaming
     // column sum instead of a fifth MFMA tile row (no change: the kernel is latency-, not MFMA-bound), dX on a
     // pre-transposed copy of W so that its B operand stages with 16-byte LDS stores like the forward's (no change),
     // two register-staged k-tiles in flight for the skinny streaming shapes (C4 1.03 -> 1.10 ms, C2 0.166 -> 0.176).
     if (g.M >= 128 && g.N >= 128 && g.K >= 128 && (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * splits >= 512)
-        return launch_shape<A_KCONT, B_KCONT, EPI, 2, 2, 16, 2, 2>(g, splits, st);
+        return launch_shape<A_KCONT, B_KCONT, EPI, 2, 2, 32, 2, 2>(g, splits, st);
     return launch_shape<A_KCONT, B_KCONT, EPI, 2, 2, 16>(g, splits, st);                    // 64 x 64
 }
 
