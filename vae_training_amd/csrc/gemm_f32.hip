@@ -182,26 +182,29 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
 
-    float ra[(BM * BK / 4 + NT - 1) / NT][4], rb[(BN * BK / 4 + NT - 1) / NT][4];
+    // Register staging: one k-tile ahead, or TWO for the tall-skinny streaming shape (128 x 32 tile, a few hundred
+    // workgroups = one per CU: a single 16 KB tile in flight per CU cannot cover HBM latency).
+    constexpr bool DEEP = (WM == 4 && EPI != EPI_DW);
+    constexpr int NSET = DEEP ? 2 : 1;
+    float ra[NSET][(BM * BK / 4 + NT - 1) / NT][4], rb[NSET][(BN * BK / 4 + NT - 1) / NT][4];
     // does this workgroup's tile lie fully inside each operand (rows / columns; the k range is checked per k-tile)?
     const bool a_in = a_vec && (A_KCONT ? m0 + BM <= g.M : m0 + BM <= g.a_mem);
     const bool b_in = b_vec && n0 + BN <= g.N;
-    auto fetch = [&](int k0) {
+    auto fetch = [&](int k0, int set) {
         const bool k_in = k0 + BK <= kend;                 // uniform: a scalar branch
-        if (a_in && k_in) { if (A_KCONT) fetch_kcont_full<BM, BK>(g.A, g.lda, m0, k0, ra); else fetch_mncont_full<BM, BK>(g.A, g.lda, m0, k0, ra); }
-        else if (A_KCONT) fetch_kcont<BM, BK>(g.A, g.lda, m0, g.M, k0, kend, a_vec, ra);
-        else fetch_mncont<BM, BK>(g.A, g.lda, m0, g.a_mem, EPI == EPI_DW, k0, kend, a_vec, ra);
-        if (b_in && k_in) { if (B_KCONT) fetch_kcont_full<BN, BK>(g.B, g.ldb, n0, k0, rb); else fetch_mncont_full<BN, BK>(g.B, g.ldb, n0, k0, rb); }
-        else if (B_KCONT) fetch_kcont<BN, BK>(g.B, g.ldb, n0, g.N, k0, kend, b_vec, rb);
-        else fetch_mncont<BN, BK>(g.B, g.ldb, n0, g.N, false, k0, kend, b_vec, rb);
+        if (a_in && k_in) { if (A_KCONT) fetch_kcont_full<BM, BK>(g.A, g.lda, m0, k0, ra[set]); else fetch_mncont_full<BM, BK>(g.A, g.lda, m0, k0, ra[set]); }
+        else if (A_KCONT) fetch_kcont<BM, BK>(g.A, g.lda, m0, g.M, k0, kend, a_vec, ra[set]);
+        else fetch_mncont<BM, BK>(g.A, g.lda, m0, g.a_mem, EPI == EPI_DW, k0, kend, a_vec, ra[set]);
+        if (b_in && k_in) { if (B_KCONT) fetch_kcont_full<BN, BK>(g.B, g.ldb, n0, k0, rb[set]); else fetch_mncont_full<BN, BK>(g.B, g.ldb, n0, k0, rb[set]); }
+        else if (B_KCONT) fetch_kcont<BN, BK>(g.B, g.ldb, n0, g.N, k0, kend, b_vec, rb[set]);
+        else fetch_mncont<BN, BK>(g.B, g.ldb, n0, g.N, false, k0, kend, b_vec, rb[set]);
     };
-    if (kbeg < kend) fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    auto stage_and_multiply = [&](int k0, int set) {
         __syncthreads();                       // previous tile fully consumed
-        if (A_KCONT) store_kcont<BM, BK>(As, ra); else store_mncont<BM, BK>(As, ra);
-        if (B_KCONT) store_kcont<BN, BK>(Bs, rb); else store_mncont<BN, BK>(Bs, rb);
+        if (A_KCONT) store_kcont<BM, BK>(As, ra[set]); else store_mncont<BM, BK>(As, ra[set]);
+        if (B_KCONT) store_kcont<BN, BK>(Bs, rb[set]); else store_mncont<BN, BK>(Bs, rb[set]);
         __syncthreads();
-        if (k0 + BK < kend) fetch(k0 + BK);    // in flight under the MFMAs below
+        if (k0 + NSET * BK < kend) fetch(k0 + NSET * BK, set);    // in flight under the MFMAs below (and the next tile's)
         const float* pa = As + (lane >> 5) * SA + wm * 32 * TM + (lane & 31);
         const float* pb = Bs + (lane >> 5) * SB + wn * 32 * TN + (lane & 31);
 #pragma unroll
@@ -217,6 +220,12 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
                 for (int jn = 0; jn < TN; ++jn)
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[jn], acc[i][jn], 0, 0, 0);
         }
+    };
+    if (kbeg < kend) fetch(kbeg, 0);
+    if (DEEP && kbeg + BK < kend) fetch(kbeg + BK, 1);
+    for (int k0 = kbeg; k0 < kend; k0 += NSET * BK) {
+        stage_and_multiply(k0, 0);
+        if (DEEP && k0 + BK < kend) stage_and_multiply(k0 + BK, 1);
     }
     // C/D map of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float e_mse = 0.f, e_deps = 0.f, e_inv_var = 0.f, e_sigma = 0.f, e_dscale = 0.f;
@@ -337,7 +346,8 @@ static int launch(const GemmArgs& g, int splits, hipStream_t st) {
     // workgroups a whole number per CU (2 per CU: 15 % slower than 2.4), the ones row of [X | 1]^T as a streaming
     // column sum instead of a fifth MFMA tile row (no change: the kernel is latency-, not MFMA-bound), dX on a
     // pre-transposed copy of W so that its B operand stages with 16-byte LDS stores like the forward's (no change),
-    // two register-staged k-tiles in flight for the skinny streaming shapes (C4 1.03 -> 1.10 ms, C2 0.166 -> 0.176).
+    // (two register-staged k-tiles in flight lost 7 % while the fetch was serialised; with the full-tile fetch they win for
+    // the tall-skinny forward / dX shape -- C4 0.966 -> 0.933 ms -- and still lose slightly for the dW shapes).
     if (g.M >= 128 && g.N >= 128 && g.K >= 128 && (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * splits >= 512)
         return launch_shape<A_KCONT, B_KCONT, EPI, 2, 2, 32, 2, 2>(g, splits, st);
     return launch_shape<A_KCONT, B_KCONT, EPI, 2, 2, 16>(g, splits, st);                    // 64 x 64
