@@ -182,16 +182,53 @@ def cpu_baseline(w, B, seconds):
     return out
 
 
+def cpu_baseline_c1(seconds_each=1.5):
+    """BASELINE config 1 (the reference's own CPU-runnable case, seed_linpadding_expts.sh:1 at run.py:14's batch sizes) on the
+    host cores: the C port at B = 128 (BASELINE.json) and 100 (the script default), latent 2 (BASELINE.json) and 20 (the
+    script).  One thread: at these sizes a step is ~100 kflop and OpenMP's fork/join costs more than it."""
+    from oracle import elbo_oracle as O
+    from oracle import elbo_ref as R
+    lib = R.load(native=True)
+    legs = []
+    for B in (128, 100):
+        for L in (2, 20):
+            cfg = O.Config(12, L, (), (), -1.0, True, "linear_gaussian")
+            rng = np.random.default_rng(1)
+            x = rng.standard_normal((B, 12)).astype(np.float32); z1 = rng.standard_normal((B, L)).astype(np.float32)
+            z2 = rng.standard_normal((B, 12)).astype(np.float32)
+            c = R.make_cfg(12, L, (), (), -1.0, True, False)
+            P = cfg.n_params()
+            params = np.ascontiguousarray(O.flatten(cfg, O.init_params(cfg, seed=0)), dtype=np.float32)
+            m = np.zeros(P, np.float32); v = np.zeros(P, np.float32)
+            for t in (1, 2):
+                R.step(lib, c, params, m, v, t, x, z1, z2, 1e-3, nthreads=1)
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < seconds_each and n < 2000000:
+                for _ in range(200):
+                    R.step(lib, c, params, m, v, 3 + n, x, z1, z2, 1e-3, nthreads=1)
+                    n += 1
+            dt = time.perf_counter() - t0
+            legs.append({"batch": B, "latent_dim": L, "value": B * n / dt, "unit": "samples/s", "us_per_step": dt / n * 1e6,
+                         "cores": 1, "kind": "port", "sample": f"{n} train steps, C float32 port, 1 thread, {dt:.1f} s wall "
+                                                               "(includes ~1 us of ctypes call overhead per step)"})
+    return legs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=960)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--workload", default="M", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (weak) / global batch (strong); 0 = workload default")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--comm", default="auto", choices=["auto", "rccl", "p2p"])
-    ap.add_argument("--nbuf", type=int, default=4, help="rotating synthetic input batches resident in HBM")
+    ap.add_argument("--nbuf", type=int, default=0,
+                    help="rotating synthetic input batches resident in HBM; 0 = auto: enough that one rotation (>= 600 MB, at most 48 "
+                         "batches) cannot stay in the 256 MiB Infinity Cache")
+    ap.add_argument("--keep-mall", action="store_true",
+                    help="do not sweep the Infinity Cache before the timed region (default: a 1 GiB fill evicts the inputs the warm-up "
+                         "steps left there, so the timed steps read them from HBM)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -200,7 +237,7 @@ def main():
                     help="multi-rank rehearsal on a ONE-GPU box: every rank uses cuda:0 and the process group is gloo")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="Dense GEMM arithmetic (bf16: wide layers on bf16 MFMA)")
     ap.add_argument("--graph", type=int, default=-1,
-                    help="steps captured per hipGraph (0 = eager launches; -1 = auto: the largest nbuf-multiple <= 200 dividing --steps)")
+                    help="steps captured per hipGraph (0 = eager launches; -1 = auto: the largest even size <= 200 dividing --steps)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -241,7 +278,10 @@ def main():
     grads = eng.new_flat(eng.grad_len)
     m, v = eng.new_flat(), eng.new_flat()
     step_dev = torch.zeros(1, dtype=torch.int32, device=device)
-    batches = make_batches(w, B_local, device, args.nbuf, seed=1000 + rank)
+    batch_bytes = B_local * 4 * (2 * D + L)
+    nbuf = args.nbuf if args.nbuf > 0 else int(min(48, max(4, math.ceil(600e6 / batch_bytes))))
+    batches = make_batches(w, B_local, device, nbuf, seed=1000 + rank)
+    mall_sweep = None if args.keep_mall else torch.empty(1 << 28, dtype=torch.float32, device=device)     # 1 GiB
     exch = GradExchange(eng, dist, mode=args.comm) if world > 1 else None
     lr = w["lr"]
 
@@ -271,9 +311,8 @@ def main():
             gsteps = 0
         else:
             # a graph launch costs ~6 us of its own (13.40 us/step at 20 steps per graph, 13.15 at 200): capture the largest
-            # multiple of the batch rotation <= 200 that divides K (or leaves the fewest eager steps over)
-            nb = len(batches)
-            cands = [g for g in range(200 // nb * nb, 0, -nb) if g <= max(args.steps, nb)]
+            # size <= 200 that divides K (or leaves the fewest eager steps over); step i of a replay reads batch i % nbuf
+            cands = [g for g in range(200, 0, -2) if g <= max(args.steps, 2)]      # even: the fresh-input leg alternates two buffers
             gsteps = min(cands, key=lambda g: (args.steps % g, -g))          # fewest eager left-over steps, then the largest
     graph = None
     n_warm_eager = max(args.warmup, 3)
@@ -301,6 +340,11 @@ def main():
         for i in range(n - done):
             one_step(i)
 
+    def sweep():            # evict whatever the untimed steps left in the Infinity Cache: the timed steps start from HBM
+        if mall_sweep is not None:
+            mall_sweep.fill_(1.0)
+
+    sweep()
     fence()
     t0 = time.perf_counter()
     run_steps(args.steps)
@@ -315,41 +359,65 @@ def main():
     if exch is not None and exch.in_library:
         assert not exch.timed_out(), "p2p gradient exchange gave up waiting for a peer"
 
-    # ---- roofline leg: the same K steps again with every library launch bracketed by hipEvents ----
+    # ---- roofline leg: the same steps again with every library launch bracketed by its own begin/end timestamps ----
     roofline = None
     if not args.no_roofline:
-        rsteps = min(args.steps, 200)                       # kernel-timestamp leg: 200 steps are plenty (one event pair per launch)
+        rsteps = min(args.steps, 192)                       # kernel-timestamp leg (one event pair per launch)
+        sweep()
         eng.profile_begin(max_records=rsteps * 64)
         for i in range(rsteps):
             one_step(i)
         torch.cuda.synchronize()
         rep = eng.profile_report()
         if rep:
-            dom = max(rep, key=lambda k: rep[k]["total_ms"])
-            avg_s = rep[dom]["total_ms"] / rep[dom]["count"] * 1e-3
-            per_step = rep[dom]["count"] / rsteps            # launches of the dominant kernel per step
             P = eng.P
-            if flops_per_sample(w) / (4.0 * (2 * D + L)) > 300.0:   # above the f32/bf16 ridge: MFMA-bound (C3)
-                # layer-by-layer path: the Dense kernels run once per layer; price the step's flops against the
-                # time of all Dense launches of a step (kernel_avg_us stays the dominant kernel's own average)
+            dom = max(rep, key=lambda k: rep[k]["total_ms"])
+            dom_avg_s = rep[dom]["total_ms"] / rep[dom]["count"] * 1e-3
+            step_kernels_s = sum(r["total_ms"] for r in rep.values()) / rsteps * 1e-3      # all launches of one step
+            step_wall_s = elapsed / args.steps
+            mfma_bound = flops_per_sample(w) / (4.0 * (2 * D + L)) > 300.0             # above the ridge: C3
+            if mfma_bound:
+                # layer-by-layer path: the Dense kernels run once per layer; the step's flops are priced against the time
+                # of all Dense launches of a step
                 alg = B_local * flops_per_sample(w)
-                gemm_s = sum(r["total_ms"] for k, r in rep.items() if k.startswith("gemm")) / rsteps * 1e-3
-                peak, unit, bound = (2500.0 if args.dtype == "bf16" else 157.3), "TFLOP/s", "mfma"
-                achieved = alg / gemm_s / 1e12
+                kernel_s = sum(r["total_ms"] for k, r in rep.items() if k.startswith("gemm")) / rsteps * 1e-3
+                kernel_name = "all Dense (gemm_*) launches of a step"
+                peak, unit, bound, scale = (2500.0 if args.dtype == "bf16" else 157.3), "TFLOP/s", "mfma", 1e12
+                alg_step = alg
             else:
-                alg = B_local * 4 * (2 * D + L)
-                peak, unit, bound = 8000.0, "GB/s", "hbm"
-                achieved = alg / avg_s / 1e9
+                alg = B_local * 4 * (2 * D + L)              # x, z1, z2 read once; + 32 P per step
+                alg_step = alg + 32 * P
+                peak, unit, bound, scale = 8000.0, "GB/s", "hbm", 1e9
+                if eng.fused:
+                    # one kernel reads every algorithmic input byte: price THAT kernel by its own duration
+                    kernel_s, kernel_name = dom_avg_s, dom
+                else:
+                    # multi-kernel path: the algorithmic bytes are spread over all launches of the step, so the
+                    # denominator is their summed duration (one kernel's duration would overstate the rate)
+                    alg = alg_step
+                    kernel_s, kernel_name = step_kernels_s, "all launches of a step (layer-by-layer path)"
+            achieved = alg / kernel_s / scale
             traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh)
-            tfile = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{args.workload}.json")
-            if os.path.exists(tfile) and B_local == w["batch"]:
-                traffic = json.load(open(tfile))["kernels"].get(dom, {}).get("traffic_bytes")
+            for rnd in ("r02", "r01"):
+                tfile = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{args.workload}.json")
+                if os.path.exists(tfile) and B_local == w["batch"] and args.dtype == "f32":
+                    kern = json.load(open(tfile))["kernels"]
+                    traffic = kern.get(dom, {}).get("traffic_bytes") if eng.fused else \
+                        (sum(v.get("traffic_bytes_per_step", 0) for v in kern.values()) or None)
+                    break
             roofline = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
-                        "traffic": traffic, "kernel": dom, "kernel_avg_us": avg_s * 1e6,
-                        "launches_per_step": rep[dom]["count"] / rsteps,
+                        "traffic": traffic, "kernel": kernel_name, "kernel_avg_us": kernel_s * 1e6,
+                        "dominant_kernel": dom, "dominant_kernel_avg_us": dom_avg_s * 1e6,
+                        "launches_per_step": sum(r["count"] for r in rep.values()) / rsteps,
                         "algorithmic_per_launch": alg,
+                        # the same algorithmic work priced against the whole step's wall time (launch gaps, finalize, Adam
+                        # included): what `value` corresponds to
+                        "step_level": {"algorithmic_per_step": alg_step, "step_us": step_wall_s * 1e6,
+                                       "achieved": alg_step / step_wall_s / scale, "frac": alg_step / step_wall_s / scale / peak},
                         "step_kernels_us": {k: r["total_ms"] / rsteps * 1e3 for k, r in rep.items()},
-                        "param_bytes_per_step": 32 * P}
+                        "param_bytes_per_step": 32 * P,
+                        "inputs": f"{nbuf} rotating batches = {nbuf * batch_bytes / 1e6:.0f} MB per rotation"
+                                  + ("" if args.keep_mall else ", Infinity Cache swept before the timed steps")}
             if rank == 0:       # the same denominators re-measured on THIS box by the library's micro-benchmarks
                 roofline["peak_measured"] = eng.measure_peaks()
                 roofline["peak_measured"]["empty_kernel_launch_interval_us_in_hipGraph"] = eng.measure_launch_floor()
@@ -396,6 +464,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(w, B_local, args.cpu_seconds)
+        if args.workload == "M":
+            cpu["c1"] = cpu_baseline_c1()
 
     if rank == 0:
         value = B_global * args.steps / elapsed
@@ -407,7 +477,7 @@ def main():
             "config": {"workload": f"{args.workload}: {w['desc']}", "batch_per_gpu": B_local, "global_batch": B_global,
                        "data_dim": D, "latent_dim": L, "params": eng.P, "path": "fused" if eng.fused else "layer-by-layer",
                        "parallelism": f"dp{world}", "grad_exchange": (exch.mode if exch else "none"),
-                       "launch": (f"hipGraph x{gsteps} steps" if graph is not None else "eager"),
+                       "launch": (f"hipGraph x{gsteps} steps" if graph is not None else "eager"), "input_batches": nbuf,
                        "final_loss": loss},
             "roofline": roofline, "cpu_baseline": cpu, "fresh_inputs_each_step": fresh,
         }

@@ -94,6 +94,59 @@ def test_param_tree_init_and_checkpoint_roundtrip():
             model(torch.zeros(4, 7), torch.zeros(4, 6), torch.zeros(4, 7))
 
 
+def test_checkpoint_loader_executes_nothing_and_validates(tmp_path):
+    """--state_dict (model.py:37-43 in the reference, dead there): a checkpoint this package wrote loads through the
+    restricted unpickler; a pickle that would call into anything else is refused without running it; a checkpoint of
+    another architecture is refused with a readable message."""
+    import pickle
+
+    from vae_training_amd import random as vr
+    from vae_training_amd.model import load_checkpoint
+    from vae_training_amd.networks import VAE, Model
+    from vae_training_amd.optim import Adam
+    mod = VAE.partial(epsilon=-1.0, encoder_layer_sizes=[8, 4], decoder_layer_sizes=[8, 5], tunable_decoder_var=True,
+                      dataset_name="linear_gaussian", device="cpu")
+    opt = Adam(learning_rate=1e-3).create(Model(mod, mod.init_by_shape(vr.PRNGKey(0), [(5,), (4,), (5,)])[1]))
+    opt.state.step = 3
+    fn = tmp_path / "model.pkl"
+    with open(fn, "wb") as f:
+        pickle.dump(opt.state_dict(), f)
+    sd = load_checkpoint(fn)
+    assert sd["state"]["step"] == 3 and sd["target"]["params"]["Encoder"]["FC0"]["kernel"].shape == (5, 8)
+    Adam(learning_rate=1e-3).create(Model(mod, mod.init_by_shape(vr.PRNGKey(1), [(5,), (4,), (5,)])[1])).load_state_dict(sd)
+
+    marker = tmp_path / "pwned"
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, (f"touch {marker}",))
+    bad = tmp_path / "evil.pkl"
+    with open(bad, "wb") as f:
+        pickle.dump({"target": Evil()}, f)
+    with pytest.raises(pickle.UnpicklingError):
+        load_checkpoint(bad)
+    assert not marker.exists()
+
+    other = VAE.partial(epsilon=-1.0, encoder_layer_sizes=[16, 4], decoder_layer_sizes=[8, 5], tunable_decoder_var=True,
+                        dataset_name="linear_gaussian", device="cpu")
+    opt3 = Adam(learning_rate=1e-3).create(Model(other, other.init_by_shape(vr.PRNGKey(0), [(5,), (4,), (5,)])[1]))
+    with pytest.raises(ValueError, match="Encoder/FC0/kernel"):
+        opt3.load_state_dict(sd)
+    with pytest.raises(ValueError, match="not a checkpoint"):
+        opt3.load_state_dict({"params": {}})
+
+
+def test_wide_manifold_datasets_fall_back_to_the_torch_draw():
+    """-dd / -did above the device generator's 16 (csrc/rng.hip) still work: get_batch takes the torch draw."""
+    from vae_training_amd import datasets
+    ds = datasets.LinearGaussianDataset(2, dimension=32, intrinsic_dimension=20, padding_dimension=4, device="cpu")
+    assert ds.device_spec()[2] > datasets.DEVICE_DRAW_MAX_DIM
+    ds.device = torch.device("cuda")            # even on a GPU host the device draw is skipped for this width ...
+    assert ds._device_batch(8) is None          # ... before anything touches the GPU
+    ds.device = torch.device("cpu")
+    assert ds.get_batch(8).shape == (8, 36)
+
+
 def test_random_keys():
     from vae_training_amd import random as vr
     k = vr.PRNGKey(0)

@@ -316,8 +316,11 @@ static thread_local int g_last_bm = 0, g_last_nbx = 0;      // tile rows / tile 
 
 template <bool A_KCONT, bool B_KCONT, int EPI, int WM, int WN, int BK, int TM = 1, int TN = 1>
 static int launch_shape(const GemmArgs& g, int splits, hipStream_t st) {
-    ProfScope ps(EPI == EPI_FWD ? "gemm_f32_fwd" : EPI == EPI_REPARAM ? "gemm_f32_fwd_reparam"
-                 : EPI == EPI_DX ? "gemm_f32_dx" : EPI == EPI_ELBO ? "gemm_f32_fwd_elbo" : "gemm_f32_dw", st);
+    // the 128 x 128 register-blocked shape carries its own label, so that tests can assert it ran (tests/test_gpu_wide.py)
+    constexpr bool BIG = TM == 2 && TN == 2;
+    ProfScope ps(EPI == EPI_FWD ? (BIG ? "gemm_f32_fwd_128x128" : "gemm_f32_fwd") : EPI == EPI_REPARAM ? "gemm_f32_fwd_reparam"
+                 : EPI == EPI_DX ? (BIG ? "gemm_f32_dx_128x128" : "gemm_f32_dx") : EPI == EPI_ELBO ? "gemm_f32_fwd_elbo"
+                 : (BIG ? "gemm_f32_dw_128x128" : "gemm_f32_dw"), st);
     dim3 grid((g.N + 32 * WN * TN - 1) / (32 * WN * TN), (g.M + 32 * WM * TM - 1) / (32 * WM * TM), splits);
     if (grid.y > 65535u || grid.z > 65535u) {
         set_error("gemm grid too large (M=%d N=%d splits=%d)", g.M, g.N, splits);

@@ -12,6 +12,9 @@ import torch
 from . import random as vrandom
 
 
+DEVICE_DRAW_MAX_DIM = 16      # csrc/rng.hip make_batch_args: -dd / -did above this are drawn with torch ops instead
+
+
 def _device():
     return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
 
@@ -34,11 +37,13 @@ class DistributionDataset:
         """x[size, ndim] from vaek_make_batch (kind/A/dd/did/pad of device_spec), or None on a CPU-only host."""
         if self.device.type != "cuda":
             return None
+        kind, A, dd, did, pad, var = self.device_spec()
+        if dd > DEVICE_DRAW_MAX_DIM or did > DEVICE_DRAW_MAX_DIM:
+            return None         # vaek_make_batch keeps a row's normals in registers (dd, did <= 16): wider manifolds use the torch draw
         from .engine import Engine
         eng = getattr(self, "_util_engine", None)
         if eng is None:
             eng = self._util_engine = Engine(1, self.ndim, 1, device=self.device.index)   # carries no model: x-only draws
-        kind, A, dd, did, pad, var = self.device_spec()
         self._draws += 1
         x, _, _ = eng.make_batch(kind, A, dd, did, pad, var, size, seed=self.key[0] ^ self.key[1], step=self._draws, tag=1,
                                  want_z=False)

@@ -214,7 +214,7 @@ class Engine:
         scratch = torch.zeros(16, dtype=torch.float32, device=self.device)
         flops = C.c_double()
         st = _stream()
-        plan = [("microbench_mfma_f32", 0, 4000, 2), ("microbench_mfma_bf16", 1, 4000, 2)]
+        plan = [("microbench_mfma_f32", 0, 20000, 1), ("microbench_mfma_bf16", 1, 40000, 1)]     # ~1 ms each, one wave per SIMD
         for _ in range(2):                                   # warm-up
             _lib.check(self.lib.vaek_microbench_copy(self.h, _ptr(src), _ptr(dst), copy_bytes, st))
             for _, kind, iters, wps in plan:

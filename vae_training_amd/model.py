@@ -15,6 +15,30 @@ import torch
 from . import random as vrandom
 
 
+class _CheckpointUnpickler(pickle.Unpickler):
+    """Unpickler for model.pkl (save_model below / model.py:85-89): nested dicts of numpy arrays plus an int step.
+    Only the globals numpy needs to rebuild an ndarray (and OrderedDict) resolve; anything else -- i.e. any pickle
+    that would run code on load -- raises instead of executing."""
+    _ALLOWED = {
+        ("collections", "OrderedDict"),
+        ("numpy", "ndarray"), ("numpy", "dtype"),
+        ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+        ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+        ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),
+    }
+
+    def find_class(self, module, name):
+        if (module, name) not in self._ALLOWED:
+            raise pickle.UnpicklingError(f"checkpoint refers to {module}.{name}: only dict / list / int / float / "
+                                         "numpy.ndarray checkpoints written by this package are loaded")
+        return super().find_class(module, name)
+
+
+def load_checkpoint(path):
+    with open(path, "rb") as f:
+        return _CheckpointUnpickler(f).load()
+
+
 class Model:
     def __init__(self, dirname, batch_size, learning_rate, state_dict, tqdm=False):
         self.dirname, self.batch_size, self.learning_rate = dirname, batch_size, learning_rate
@@ -32,8 +56,7 @@ class Model:
         if self.optimizer is None or self.state_dict is None:
             return
         if isinstance(self.state_dict, (str, os.PathLike)):
-            with open(self.state_dict, "rb") as f:
-                self.state_dict = pickle.load(f)           # a checkpoint THIS package wrote (save_model)
+            self.state_dict = load_checkpoint(self.state_dict)      # a checkpoint THIS package wrote (save_model)
         self.optimizer.load_state_dict(self.state_dict)
         self.model = self.optimizer.target
 
@@ -128,6 +151,50 @@ class GenerativeModel(Model):
     def train(self):
         self.train_distribution()
 
+    # ---- data-parallel hygiene around the rank-0-only work (plot + save) -------------------------------------------
+    def _dp_exchange(self):
+        opt = getattr(self, "optimizer", None)
+        ex = getattr(opt, "exchange", None)
+        return ex if ex is not None and getattr(ex, "world", 1) > 1 else None
+
+    def _dp_sync(self):
+        """Every rank waits here after a block only rank 0 executes (matplotlib import, font cache, pickling can take
+        seconds): without it the other ranks would enter the next step's in-kernel exchange and spin towards its
+        give-up bound while rank 0 is still on the host."""
+        ex = self._dp_exchange()
+        if ex is not None:
+            torch.cuda.synchronize()
+            ex.dist.barrier()
+
+    def check_replicas(self):
+        """Data-parallel replicas apply the same update to the same sums: parameters and Adam moments must be BITWISE equal
+        on every rank.  Compared through an element-wise MAX and MIN over ranks."""
+        ex = self._dp_exchange()
+        if ex is None:
+            return True
+        st = self.optimizer.state
+        for name, t in (("params", self.model.flat), ("m", st.m), ("v", st.v)):
+            hi = t.detach().clone() if ex.dist.get_backend() != "gloo" else t.detach().cpu()
+            lo = hi.clone()
+            ex.dist.all_reduce(hi, op=ex.dist.ReduceOp.MAX)
+            ex.dist.all_reduce(lo, op=ex.dist.ReduceOp.MIN)
+            if not torch.equal(hi, lo):
+                raise RuntimeError(f"data-parallel replicas diverged: {name} differ between ranks "
+                                   f"(max |difference| {float((hi - lo).abs().max()):.3e})")
+        self._write(f"Data parallel: replicas identical on {ex.world} ranks after {self.optimizer.state.step} steps")
+        return True
+
+    def _dp_check(self):
+        """An in-kernel exchange that gave up waiting for a peer has summed a stale granule: the replicas may have
+        diverged, so stop loudly (every rank takes the same decision)."""
+        ex = self._dp_exchange()
+        if ex is None or not ex.in_library:
+            return
+        torch.cuda.synchronize()
+        if not ex._all_ok(not ex.timed_out()):
+            raise RuntimeError("data-parallel gradient exchange gave up waiting for a peer (vaek_comm_status): "
+                               "replicas may have diverged; aborting")
+
     def train_distribution(self):
         """model.py:207-222: stats every n_print steps, plot+save every n_plot steps and at the end,
         one dataset batch + one train step per iteration."""
@@ -146,11 +213,15 @@ class GenerativeModel(Model):
             return self._train_distribution_fast()
         for self.batchnum in it:
             if self.batchnum % self.n_print == 0:
+                self._dp_check()
                 self.write_stats(self.compute_stats())
             if self.batchnum % self.n_plot == 0 or self.batchnum == self.num_batches - 1:
+                self._dp_check()
                 self.plot_epoch()
                 self.save()
+                self._dp_sync()
             self.train_one_batch(self.dataset.get_batch(self.batch_size))
+        self._dp_check()
 
     def _train_distribution_fast(self):
         """Same schedule (stats every n_print, plot+save every n_plot and at the last step), but the steps in
@@ -165,12 +236,15 @@ class GenerativeModel(Model):
             loop.run(ev - pos)
             pos = ev
             self.batchnum = ev
+            self._dp_check()
             if ev % self.n_print == 0:
                 self.write_stats(self.compute_stats())
             if ev % self.n_plot == 0 or ev == self.num_batches - 1:
                 self.plot_epoch()
                 self.save()
+                self._dp_sync()
         loop.run(self.num_batches - pos)
+        self._dp_check()
 
     def save(self, final=False):
         if getattr(self, "rank", 0) != 0:          # replicas are identical: rank 0 writes losses.npz / model.pkl

@@ -168,9 +168,14 @@ class VAE:
         lr = optimizer.optimizer_def.learning_rate
         if optimizer.exchange is None or optimizer.exchange.in_library:
             eng.train_step(model.flat, st.grads, st.m, st.v, st.step_dev, x, z1, z2, lr)
-        else:
+        elif eng.fused:
             eng.grads_only(model.flat, st.grads, st.step_dev, x, z1, z2)
             optimizer.exchange.all_reduce(st.grads)
+            eng.apply(model.flat, st.grads, st.m, st.v, st.step_dev, lr)
+        else:
+            # layer-by-layer model over RCCL: per-layer gradient buckets all-reduced on a side stream while the
+            # backward GEMMs of the earlier layers still run
+            optimizer.exchange.overlapped_grads(model.flat, st.grads, st.step_dev, x, z1, z2)
             eng.apply(model.flat, st.grads, st.m, st.v, st.step_dev, lr)
         st.step += 1
         new_model = Model(model.module, None, _flat=model.flat)

@@ -65,6 +65,7 @@ class Optimizer:
         from . import layout
         from .networks import _copy_tree
         lv = self.target.module.leaves
+        _validate_checkpoint(sd, self.target.params)
         _copy_tree(sd["target"]["params"], self.target.params)
         ps = sd["state"]["param_states"]
         pick = lambda tree, key: {k: (pick(v, key) if "grad_ema" not in v else v[key]) for k, v in tree.items()}
@@ -73,3 +74,31 @@ class Optimizer:
         self.state.step = int(sd["state"]["step"])
         self.state.step_dev.fill_(self.state.step)
         return self
+
+
+def _validate_checkpoint(sd, params):
+    """Key set and leaf shapes of a checkpoint against this model's parameter tree, with a readable error (a mismatched
+    architecture would otherwise fail deep inside the copy into the flat views)."""
+    import numpy as np
+    try:
+        tree, ps, step = sd["target"]["params"], sd["state"]["param_states"], sd["state"]["step"]
+    except (KeyError, TypeError) as e:
+        raise ValueError("not a checkpoint written by vae_training_amd (expected {'target': {'params'}, 'state': {'step', "
+                         "'param_states'}})") from e
+    if not isinstance(step, (int, np.integer)) or step < 0:
+        raise ValueError(f"checkpoint step {step!r} is not a non-negative integer")
+
+    def walk(want, got, moments, path):
+        if set(want) != set(got) or set(want) != set(moments):
+            raise ValueError(f"checkpoint does not match this architecture at {path or '/'}: has {sorted(got)}, model has {sorted(want)}")
+        for k, v in want.items():
+            if isinstance(v, dict):
+                walk(v, got[k], moments[k], f"{path}/{k}")
+                continue
+            leaves = [("params", got[k])] + [(n, moments[k].get(n) if isinstance(moments[k], dict) else None)
+                                            for n in ("grad_ema", "grad_sq_ema")]
+            for what, a in leaves:
+                shape = tuple(np.shape(a)) if a is not None else None
+                if shape != tuple(v.shape):
+                    raise ValueError(f"checkpoint leaf {path}/{k} ({what}) has shape {shape}, model expects {tuple(v.shape)}")
+    walk(params, tree, ps, "")

@@ -44,6 +44,9 @@ def build_parser():
     p.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="Dense GEMM arithmetic (bf16: wide layers on bf16 MFMA)")
     p.add_argument("--dist_backend", default="nccl", choices=["nccl", "gloo"],
                    help="process-group backend when launched with torch.distributed.run (gloo: one-GPU rehearsal)")
+    p.add_argument("--comm", default="auto", choices=["auto", "rccl", "p2p"],
+                   help="data-parallel gradient exchange: in-kernel peer-to-peer granules (small models) or RCCL all-reduce "
+                        "of per-layer buckets overlapped with the backward pass")
     p.add_argument("--fast_loop", action="store_true",
                    help="run the steps between stats/plots from a hipGraph with on-device Philox batches (trainer.py)")
     return p
@@ -112,7 +115,10 @@ def _get_model_dp(args, dataset, output_dir, dist, world, rank):
                  latent_off_dimension=args.latent_off_dimension, force_generic=getattr(args, "force_generic", False),
                  dtype=getattr(args, "dtype", "f32"), world=world, rank=rank, global_batch=args.batch_size)
     eng = m.model.module.engine(hi - lo, args.batch_size)
-    m.optimizer.exchange = GradExchange(eng, dist)
+    m.optimizer.exchange = GradExchange(eng, dist, mode=getattr(args, "comm", "auto"))
+    if rank == 0:
+        how = m.optimizer.exchange.mode + ("" if m.optimizer.exchange.in_library or eng.fused else ", per-layer buckets overlapped with the backward pass")
+        print(f"Data parallel: world {world}, {hi - lo} rows per rank, gradient exchange {how}")
     m.key = vrandom.split(m.key, world)[rank]              # identical initial parameters, different latent draws
     m.rank = rank
     return m
@@ -144,6 +150,7 @@ def main(args):
     model.plot()
     model.save(final=True)
     if dist is not None:
+        model.check_replicas()
         dist.barrier()
         dist.destroy_process_group()
     return 0

@@ -26,6 +26,10 @@ class GraphLoop:
         self.m = m
         ds = m.dataset
         self.kind, self.A, self.dd, self.did, self.pad, self.var = ds.device_spec()
+        from .datasets import DEVICE_DRAW_MAX_DIM
+        if self.dd > DEVICE_DRAW_MAX_DIM or self.did > DEVICE_DRAW_MAX_DIM:
+            raise RuntimeError(f"--fast_loop draws its batches with libvaek's Philox kernel, which supports -dd / -did <= "
+                               f"{DEVICE_DRAW_MAX_DIM} (got {self.dd} / {self.did}); run without --fast_loop")
         self.B = m.batch_size
         self.eng = m.model.module.engine(self.B, m.optimizer.global_batch)
         ex = m.optimizer.exchange
