@@ -340,9 +340,16 @@ def main():
         for i in range(n - done):
             one_step(i)
 
-    def sweep():            # evict whatever the untimed steps left in the Infinity Cache: the timed steps start from HBM
-        if mall_sweep is not None:
-            mall_sweep.fill_(1.0)
+    def sweep():
+        """Evict whatever the untimed steps left in the 256 MiB Infinity Cache, so that the timed steps read their inputs from
+        HBM (a short run would otherwise re-read the very batches its warm-up just touched), then bring everything ELSE back to
+        its steady state -- code, parameters, Adam moments, workspace -- with a few untimed steps on batches from the far end of
+        the rotation, which a short timed run does not reach."""
+        if mall_sweep is None:
+            return
+        mall_sweep.fill_(1.0)
+        for i in range(4):
+            one_step(len(batches) - 1 - i)
 
     sweep()
     fence()

