@@ -12,7 +12,10 @@ from tests.gpu_util import dev, engine_for, host, random_problem, rel_err
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("hidden,B", [((128,), 700), ((256, 128), 1000), ((192, 64, 192), 333)])
+# (128,): one hidden layer -> only skinny layers, exact f32 kernels.  (256, 128), (192, 64, 192): every hidden width a multiple
+# of 64 -> the bf16-STORAGE mode (gemm_bf16s.hip: bf16 activations / gradients in HBM, direct-to-LDS loads, transposed LDS
+# reads for dW).  (200, 200): widths off the 64 grid -> f32 storage with the round-1 kernels (gemm_bf16.hip).
+@pytest.mark.parametrize("hidden,B", [((128,), 700), ((256, 128), 1000), ((192, 64, 192), 333), ((200, 200), 500), ((128, 128), 64 * 9 + 1)])
 @pytest.mark.parametrize("dataset", ["sphere", "sigmoid"])
 def test_bf16_dense_path_tracks_oracle(hidden, B, dataset):
     D = 7 if dataset == "sigmoid" else 6
@@ -24,7 +27,14 @@ def test_bf16_dense_path_tracks_oracle(hidden, B, dataset):
     assert not eng.fused
     params = dev(O.flatten(cfg, p)); grads = eng.new_flat(eng.grad_len)
     step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    eng.profile_begin(256)
     eng.grads_only(params, grads, step, dev(x), dev(z1), dev(z2))
+    torch.cuda.synchronize()
+    rep = eng.profile_report()
+    storage_mode = len(hidden) >= 2 and all(h % 64 == 0 for h in hidden)
+    assert any(k.startswith("gemm_bf16s_") for k in rep) == storage_mode, sorted(rep)
+    if len(hidden) >= 2 and not storage_mode:
+        assert any(k.startswith("gemm_bf16_") for k in rep), sorted(rep)
     got = host(grads)
     assert abs(got[eng.P] - loss) <= 2e-3 * abs(loss), (got[eng.P], loss)
     assert rel_err(got[:eng.P], O.flatten(cfg, g)) <= 2e-2

@@ -74,6 +74,32 @@ static T* at(void* ws, size_t off) { return reinterpret_cast<T*>(static_cast<cha
 // bandwidth-bound and carry the reparameterisation / ELBO inputs.
 static bool use_bf16(const vaek_ctx* c, int n_in, int n_out) { return c->cfg.dtype == VAEK_BF16 && n_in >= 64 && n_out >= 64; }
 
+// bf16-STORAGE mode of a stack (Net::b16, vaek_internal.h): with at least two hidden layers whose widths are all multiples
+// of 64, the hidden activations / gradients are kept as bf16 and the hidden -> hidden layers run gemm_bf16s.hip.  Other
+// stacks under dtype = VAEK_BF16 keep f32 storage and the round-1 kernels (gemm_bf16.hip) for their wide layers.
+static bool net_is_b16(const vaek_ctx* c, const Net& net) {
+    if (c->cfg.dtype != VAEK_BF16 || net.layers.size() < 3) return false;
+    for (size_t i = 0; i + 1 < net.layers.size(); ++i)
+        if (net.layers[i].n_out % 64) return false;
+    return true;
+}
+static inline __bf16* wb16(const vaek_ctx* c, void* ws, const Net& net, size_t i, bool transposed) {
+    const Layer& l = net.layers[i];
+    return reinterpret_cast<__bf16*>(static_cast<char*>(ws) + c->ws_wb16) + net.wb_off[i] + (transposed ? (int64_t)l.n_in * l.n_out : 0);
+}
+// bf16 copies (W and W^T) of every hidden -> hidden kernel, once per entry point that runs a b16 stack
+static int convert_weights(vaek_ctx* c, const float* params, void* ws, hipStream_t st) {
+    int K[24], N[24], n = 0; int64_t woff[24], ooff[24];
+    for (const Net* net : {&c->enc, &c->dec, &c->sig}) {
+        if (!net->b16) continue;
+        for (size_t i = 1; i + 1 < net->layers.size(); ++i) {
+            if (n == 24) { set_error("too many wide layers"); return VAEK_ERR_INVALID; }
+            K[n] = net->layers[i].n_in; N[n] = net->layers[i].n_out; woff[n] = net->layers[i].w_off; ooff[n] = net->wb_off[i]; ++n;
+        }
+    }
+    return launch_cvt_weights(params, reinterpret_cast<__bf16*>(static_cast<char*>(ws) + c->ws_wb16), K, N, woff, ooff, n, st);
+}
+
 // ---- forward through one Dense/relu stack; `reparam` fuses networks.py:73-74 into the last layer
 struct ElboFuse {           // decoder's last layer with the ELBO epilogue (gemm_f32.hip EPI_ELBO): inputs, and the tile map out
     const float* x; const float* z2; const float* eps_param; float eps_cli, inv_bt; float* part; int bm, nbx;
@@ -88,6 +114,20 @@ static int net_forward(vaek_ctx* c, const Net& net, const float* params, const f
         const float* b = w + (int64_t)l.n_in * l.n_out;
         float* y = at<float>(ws, net.act_off[i]);
         int rc;
+        if (net.b16) {
+            const bool last = i + 1 == net.layers.size();
+            const __bf16* h16p = reinterpret_cast<const __bf16*>(h);
+            if (i == 0) rc = launch_dense_fwd_out16(h, w, b, reinterpret_cast<__bf16*>(y), rows, l.n_in, l.n_out, l.relu, st);
+            else if (!last) rc = launch_hs_fwd(h16p, wb16(c, ws, net, i, true), b, reinterpret_cast<__bf16*>(y), rows, l.n_in, l.n_out, l.relu, st);
+            else if (ef) rc = launch_dense_fwd_elbo_in16(h16p, w, b, y, ef->x, ef->z2, ef->eps_param, ef->eps_cli, ef->inv_bt, ef->part, rows,
+                                                         l.n_in, l.n_out, &ef->bm, &ef->nbx, st);
+            else if (reparam) rc = launch_dense_fwd_reparam_in16(h16p, w, b, y, at<float>(ws, c->ws_samples), z1, params + c->off_epsp, rows,
+                                                                 l.n_in, l.n_out, st);
+            else rc = launch_dense_fwd_in16(h16p, w, b, y, rows, l.n_in, l.n_out, st);
+            if (rc) return rc;
+            h = y;
+            continue;
+        }
         const bool h16 = use_bf16(c, l.n_in, l.n_out);
         if (ef && i + 1 == net.layers.size())
             rc = launch_dense_fwd_elbo(h, w, b, y, ef->x, ef->z2, ef->eps_param, ef->eps_cli, ef->inv_bt, ef->part, rows, l.n_in,
@@ -119,9 +159,20 @@ static int net_backward(vaek_ctx* c, const Net& net, const float* params, const 
         const Layer& l = net.layers[i];
         const float* w = params + l.w_off;
         const float* h_in = i == 0 ? in : at<float>(ws, net.act_off[i - 1]);
-        const bool h16 = use_bf16(c, l.n_in, l.n_out);
-        int rc = (h16 ? launch_dense_bwd_dw_bf16 : launch_dense_bwd_dw)(h_in, d, slabs + l.w_off, slab_stride(c), l.S, l.rows_per_split,
+        const bool h16 = !net.b16 && use_bf16(c, l.n_in, l.n_out);
+        int rc;
+        if (net.b16) {
+            // hidden tensors are bf16: d is f32 only for the last layer (dL/d output), h_in is f32 only for layer 0
+            const bool last = i + 1 == (int)net.layers.size();
+            const __bf16* h_in16 = reinterpret_cast<const __bf16*>(h_in);
+            const __bf16* d16 = reinterpret_cast<const __bf16*>(d);
+            if (last) rc = launch_dense_bwd_dw_x16(h_in16, d, slabs + l.w_off, slab_stride(c), l.S, l.rows_per_split, c->B, l.n_in, l.n_out, st);
+            else if (i == 0) rc = launch_dense_bwd_dw_dy16(h_in, d16, slabs + l.w_off, slab_stride(c), l.S, l.rows_per_split, c->B, l.n_in, l.n_out, st);
+            else rc = launch_hs_dw(h_in16, d16, slabs + l.w_off, slab_stride(c), l.S, l.rows_per_split, c->B, l.n_in, l.n_out, st);
+        } else {
+            rc = (h16 ? launch_dense_bwd_dw_bf16 : launch_dense_bwd_dw)(h_in, d, slabs + l.w_off, slab_stride(c), l.S, l.rows_per_split,
                                                                         c->B, l.n_in, l.n_out, st);
+        }
         if (rc) return rc;
         if (sink) {     // this layer's [kernel | bias] slice is final once its slabs are summed: announce it
             const int64_t cnt = (int64_t)(l.n_in + 1) * l.n_out;
@@ -131,12 +182,24 @@ static int net_backward(vaek_ctx* c, const Net& net, const float* params, const 
         if (i > 0) {
             float* dx = gb[tog];
             tog ^= 1;
-            rc = (h16 ? launch_dense_bwd_dx_bf16 : launch_dense_bwd_dx)(d, w, h_in, dx, c->B, l.n_in, l.n_out, true, false, st);
+            if (net.b16) {
+                const __bf16* h_in16 = reinterpret_cast<const __bf16*>(h_in);
+                if (i + 1 == (int)net.layers.size())
+                    rc = launch_dense_bwd_dx_out16(d, w, h_in16, reinterpret_cast<__bf16*>(dx), c->B, l.n_in, l.n_out, false, st);
+                else
+                    rc = launch_hs_dx(reinterpret_cast<const __bf16*>(d), wb16(c, ws, net, i, false), h_in16, reinterpret_cast<__bf16*>(dx),
+                                      c->B, l.n_in, l.n_out, st);
+            } else {
+                rc = (h16 ? launch_dense_bwd_dx_bf16 : launch_dense_bwd_dx)(d, w, h_in, dx, c->B, l.n_in, l.n_out, true, false, st);
+            }
             if (rc) return rc;
             d = dx;
         } else if (dx_first) {
-            rc = (h16 ? launch_dense_bwd_dx_bf16 : launch_dense_bwd_dx)(d, w, nullptr, dx_first, c->B, l.n_in, l.n_out, false,
-                                                                        accumulate_first, st);
+            if (net.b16)
+                rc = launch_dense_bwd_dx_in16(reinterpret_cast<const __bf16*>(d), w, dx_first, c->B, l.n_in, l.n_out, accumulate_first, st);
+            else
+                rc = (h16 ? launch_dense_bwd_dx_bf16 : launch_dense_bwd_dx)(d, w, nullptr, dx_first, c->B, l.n_in, l.n_out, false,
+                                                                            accumulate_first, st);
             if (rc) return rc;
         }
     }
@@ -148,13 +211,14 @@ static int generic_grads(vaek_ctx* c, const float* params, int32_t* step_dev, co
     const bool sig = c->cfg.sigmoid_decoder != 0;
     const float inv_bt = (float)(1.0 / (double)c->Bt);
     int rc;
+    if ((rc = convert_weights(c, params, ws, st))) return rc;
     if ((rc = net_forward(c, c->enc, params, x, ws, c->B, true, z1, st))) return rc;
     const float* samples = at<float>(ws, c->ws_samples);
     float* mu = at<float>(ws, c->enc.act_off.back());
     float* y_lin = at<float>(ws, c->dec.act_off.back());
     const float* eps_param = c->off_eps >= 0 ? params + c->off_eps : nullptr;
     const Layer& last = c->dec.layers.back();
-    if (!sig && !use_bf16(c, last.n_in, last.n_out)) {
+    if (!sig && (c->dec.b16 || !use_bf16(c, last.n_in, last.n_out))) {
         // one decoder, exact f32 output layer: the ELBO's elementwise pass runs in that layer's epilogue -- its output never
         // goes to HBM, dL/dx_hat lands where the backward pass expects it
         ElboFuse ef{x, z2, eps_param, c->cfg.eps_cli, inv_bt, at<float>(ws, c->ws_eblk), 0, 0};
@@ -306,7 +370,26 @@ int vaek_ctx_create(const vaek_config* cfg, vaek_ctx** out) {
             if (l.S > c->S) { c->S = l.S; c->rows_per_split = l.rows_per_split; }
         }
     };
+    c->enc.b16 = net_is_b16(c, c->enc); c->dec.b16 = net_is_b16(c, c->dec); c->sig.b16 = net_is_b16(c, c->sig);
     splits(c->enc); splits(c->dec); splits(c->sig);
+    // hidden -> hidden layers of a bf16-storage stack (gemm_bf16s.hip, 128 x 128 tiles, 64-row k-tiles): ~512 workgroups
+    int64_t wb_elems = 0;
+    for (Net* net : {&c->enc, &c->dec, &c->sig}) {
+        net->wb_off.assign(net->layers.size(), 0);
+        if (!net->b16) continue;
+        for (size_t i = 1; i + 1 < net->layers.size(); ++i) {
+            Layer& l = net->layers[i];
+            const int tiles = ((l.n_in + 127) / 128) * ((l.n_out + 127) / 128);
+            const int s_target = std::min(256, std::max(1, 512 / tiles));
+            l.rows_per_split = std::max(64, (int)align_up((size_t)(c->B + s_target - 1) / s_target, 64));
+            l.S = (c->B + l.rows_per_split - 1) / l.rows_per_split;
+            net->wb_off[i] = wb_elems;
+            wb_elems += 2 * (int64_t)l.n_in * l.n_out;
+        }
+    }
+    c->S = 1; c->rows_per_split = c->B;
+    for (const Net* net : {&c->enc, &c->dec, &c->sig})
+        for (const auto& l : net->layers) if (l.S > c->S) { c->S = l.S; c->rows_per_split = l.rows_per_split; }
     if (c->enc.layers.size() + c->dec.layers.size() + c->sig.layers.size() > 32) {
         set_error("too many layers"); delete c; return VAEK_ERR_INVALID;
     }
@@ -328,6 +411,7 @@ int vaek_ctx_create(const vaek_config* cfg, vaek_ctx** out) {
     c->ws_eblk = off; off = align_up(off + (size_t)((c->B + 63) / 64) * ((c->D + 31) / 32) * 2 * sizeof(float), 256);
     c->fused = !cfg->force_generic && fused_supported(c);
     c->ws_fused = off; off = align_up(off + fused_workspace_bytes(c), 256);
+    c->ws_wb16 = off; off = align_up(off + (size_t)wb_elems * sizeof(__bf16), 256);
     c->ws_total = off;
     *out = c;
     return VAEK_OK;
@@ -588,6 +672,7 @@ int vaek_loss_eval(vaek_ctx* ctx, const float* params, const float* x, const flo
     hipStream_t st = (hipStream_t)stream;
     vaek_ctx* c = ctx;
     const bool sig = c->cfg.sigmoid_decoder != 0;
+    if ((rc = convert_weights(c, params, workspace, st))) return rc;
     if ((rc = net_forward(c, c->enc, params, x, workspace, c->B, true, z1, st))) return rc;
     const float* samples = at<float>(workspace, c->ws_samples);
     if ((rc = net_forward(c, c->dec, params, samples, workspace, c->B, false, nullptr, st))) return rc;
@@ -616,6 +701,7 @@ int vaek_forward(vaek_ctx* ctx, const float* params, const float* x, const float
     vaek_ctx* c = ctx;
     const bool sig = c->cfg.sigmoid_decoder != 0;
     const float* samples = z1;                      // sampling: mu = 0, logvar_e = 0 -> samples = z1
+    if ((rc = convert_weights(c, params, workspace, st))) return rc;
     if (!sampling) {
         if ((rc = net_forward(c, c->enc, params, x, workspace, rows, true, z1, st))) return rc;
         samples = at<float>(workspace, c->ws_samples);

@@ -1,0 +1,474 @@
+// Dense kernels of the bf16-STORAGE mode (BASELINE configs 2-3: "MLP ... bf16 ... MFMA Dense path"): hidden activations and
+// hidden gradients live in HBM as bf16, the products run on v_mfma_f32_32x32x16_bf16 with f32 accumulation
+// (flax.nn.Dense call sites networks.py:32-39 and their value_and_grad transposes, networks.py:99).
+//
+// Why storage: at width 512 a Dense layer is 256 flop per byte of f32 activation traffic -- below the bf16 ridge
+// (2.5 PF / 8 TB/s = 310 flop/B), i.e. with f32 activations (gemm_bf16.hip, round 1) the "matrix-core path" is an HBM
+// stream that converts every element on every use.  Here every hidden tensor is written once as bf16 by the epilogue
+// that produces it and consumed as bf16 -- half the bytes, no conversion in the operand path -- which makes direct
+// global -> LDS loads (global_load_lds_dwordx4: no VGPR round trip, no ds_write) possible for every operand.
+//
+//   hs_nt_kernel   C[M,N] = A[M,K] . Bt[N,K]^T, both operands k-contiguous.  Forward: A = activations, Bt = W^T (a bf16
+//                  transposed copy made once per step), epilogue + bias, relu.  dX: A = dY, Bt = W as stored ([in, out] =
+//                  [n', k']), epilogue relu mask from the layer's bf16 input.  Operands swapped in the MFMA (D = Bt A^T),
+//                  so a lane owns ONE output row and 4-column runs of it: with one v_permlane32_swap per dword the
+//                  epilogue stores 16 bytes per lane, 128 contiguous bytes per row and wave (no LDS transpose, no 2-byte
+//                  stores).
+//   hs_tn_kernel   dW|db slab[M,N] = sum over this split's rows of X[k,m] dY[k,n]: both operands are row-major [rows,
+//                  features], i.e. k-STRIDED -- the tiles are staged as they lie in memory and transposed on the way to
+//                  the registers by ds_read_b64_tr_b16.  db = 1^T dY comes from two extra MFMAs with a constant-ones A
+//                  operand in the workgroups of the first row of tiles.
+//   cvt_w_kernel   bf16 copies W and W^T of the wide layers' kernels (weights change every step; 1 MB at C3).
+//
+// Main loop (both kernels): 64-deep k-tiles, two LDS buffers, ONE barrier per k-tile -- wait for tile t (vmcnt(0)),
+// barrier, issue the loads of tile t+1 into the other buffer, multiply tile t.  LDS images are lane-linear (what
+// global_load_lds writes) with the bank swizzle applied to the per-lane SOURCE address and the same XOR on the read.
+#include "vaek_internal.h"
+
+namespace vaek {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+// 16 bytes per lane global -> LDS; the LDS side is wave-uniform base + 16 * lane
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_void_t*)gsrc, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+enum { HS_FWD = 0, HS_DX = 1 };
+
+struct HsArgs {
+    const __bf16* A; const __bf16* Bt; __bf16* C;   // A [M, K] (lda), Bt [N, K] (ldb), C [M, N] (ldc); K, N multiples of 64
+    int M, N, K, lda, ldb, ldc;
+    const float* bias; int relu;                    // FWD
+    const __bf16* aux;                              // DX: relu-mask source [M, ldc] (the layer's bf16 input), or nullptr
+};
+
+// Counted waits: s_waitcnt vmcnt(N) returns once at most N of this wave's vector-memory operations are still outstanding
+// (they retire in issue order), i.e. "everything up to tile kt has landed, the `newer` younger tiles may stay in flight".
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int P, int MAXT> __device__ __forceinline__ void wait_tiles(int newer) {       // P loads per tile, newer in [0, MAXT]
+    static_assert(P * MAXT <= 63, "vmcnt is a 6-bit counter");
+    if constexpr (MAXT == 0) wait_vmcnt<0>();
+    else if (newer >= MAXT) wait_vmcnt<P * MAXT>();
+    else wait_tiles<P, MAXT - 1>(newer);
+}
+
+// LDS image of an R-row x BK-k operand tile (BK = 64 / 32): 128- / 64-byte rows, 16-byte chunk c of row r at chunk position
+// c ^ f(r), f = (r >> 1) & 7 / (r >> 2) & 3: the 16 lanes ds_read_b128 services together (rows {0-3,12-15,20-27} /
+// {4-11,16-19,28-31} of a fragment, one chunk column) then cover all 16 chunk slots of the 256-byte bank row.
+//
+// Ring of NS stages: a k-tile's MFMAs take ~0.25 us per wave, an HBM / L2 round trip under load 1-3 us, so ONE tile of
+// prefetch (round 2's first version: 2.8 us per k-tile) is a latency chain; NS - 1 tiles are in flight while one is multiplied.
+template <int EPI, int BM, int BN, int WM, int WN, int BK, int NS>
+__global__ __launch_bounds__(64 * WM * WN) void hs_nt_kernel(const HsArgs g) {
+    constexpr int NTH = 64 * WM * WN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int RB = 2 * BK, CPR = BK / 8;                 // row bytes, 16-byte chunks per row
+    constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, BUF = A_BYTES + B_BYTES;
+    constexpr int A_PASSES = BM * CPR / NTH, B_PASSES = BN * CPR / NTH, P = A_PASSES + B_PASSES;
+    static_assert(BM * CPR % NTH == 0 && BN * CPR % NTH == 0, "whole staging passes");
+    static_assert(BK == 64 || BK == 32, "k-tile depth");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of the
+    // n-fastest tile space so that the tiles sharing an A row panel hit one L2 (speed only)
+    const unsigned tiles_n = (g.N + BN - 1) / BN, nb = gridDim.x;
+    unsigned id = blockIdx.x;
+    if (nb % 8 == 0) id = (id % 8) * (nb / 8) + id / 8;
+    const int m0 = (int)(id / tiles_n) * BM, n0 = (int)(id % tiles_n) * BN;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wv / WN, wn = wv % WN;
+    auto swz = [](int row) { return BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; };
+
+    // per-lane source of each staging pass (the swizzle lives here)
+    const __bf16* a_src[A_PASSES]; const __bf16* b_src[B_PASSES];
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+        const int p = i * NTH + t, row = p / CPR, c = (p % CPR) ^ swz(row);
+        a_src[i] = g.A + (long long)min(m0 + row, g.M - 1) * g.lda + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+        const int p = i * NTH + t, row = p / CPR, c = (p % CPR) ^ swz(row);
+        b_src[i] = g.Bt + (long long)min(n0 + row, g.N - 1) * g.ldb + c * 8;
+    }
+    auto stage = [&](int kt, int slot) {
+        char* base = smem + slot * BUF;
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) glds16(a_src[i] + kt * BK, base + (i * NTH + wv * 64) * 16);
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i) glds16(b_src[i] + kt * BK, base + A_BYTES + (i * NTH + wv * 64) * 16);
+    };
+    // fragment addresses: lane (r = lane & 31, h = lane >> 5) reads chunk 2 s + h of its row for k-step s
+    const int r = lane & 31, h = lane >> 5;
+    const int arow = wm * (BM / WM) + r, brow = wn * (BN / WN) + r;
+    const int ax = swz(arow), bx = swz(brow);
+    const int a_lo = arow * RB + ((h ^ ax) & 1) * 16, a_x6 = (ax & 6) * 16;
+    const int b_lo = brow * RB + ((h ^ bx) & 1) * 16 + A_BYTES, b_x6 = (bx & 6) * 16;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    const int nt = g.K / BK;
+#pragma unroll
+    for (int q = 0; q < NS - 1; ++q) if (q < nt) stage(q, q);
+    int slot = 0, fill = NS - 1;                          // ring positions of the tile being multiplied / being loaded
+    for (int kt = 0; kt < nt; ++kt) {
+        wait_tiles<P, NS - 2>(min(NS - 2, nt - 1 - kt));   // this wave's share of tile kt has landed ...
+        __builtin_amdgcn_s_barrier();                      // ... and everyone's; everyone is done reading tile kt - 1
+        if (kt + NS - 1 < nt) stage(kt + NS - 1, fill);    // into the slot tile kt - 1 was read from
+        const char* base = smem + slot * BUF;
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(base + a_lo + i * 32 * RB + ((32 * s) ^ a_x6));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(base + b_lo + j * 32 * RB + ((32 * s) ^ b_x6));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)      // swapped: D[n][m] -- lane & 31 = output row m, registers = columns n
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        fill = fill + 1 == NS ? 0 : fill + 1;
+    }
+
+    // ---- epilogue: register q of tile (i, j) = C[m0 + wm.. + 32 i + r][nb + 32 j + (q & 3) + 8 (q >> 2) + 4 h]
+    const int nbase = n0 + wn * (BN / WN);
+    if (nbase >= g.N) return;                      // wave-uniform: N is a multiple of 64 = the wave's column span
+    const float floor_v = g.relu ? 0.f : -__builtin_huge_valf();      // relu as one v_max with a uniform floor: no branch per value
+    float4 bias4[TN][4];
+    if (EPI == HS_FWD) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bias4[j][q] = *reinterpret_cast<const float4*>(g.bias + nbase + j * 32 + 8 * q + 4 * h);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * (BM / WM) + i * 32 + r;
+        const bool row_ok = m < g.M;
+        const long long rowoff = (long long)(row_ok ? m : g.M - 1) * g.ldc;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nj = nbase + j * 32;
+            // after the swaps lanes 0-31 own columns [8 qq, 8 qq + 8), lanes 32-63 [8 qq + 8, 8 qq + 16), qq = 0, 2
+            uint4 mask[2];
+            if (EPI == HS_DX && g.aux) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) mask[u] = *reinterpret_cast<const uint4*>(g.aux + rowoff + nj + 16 * u + 8 * h);
+            }
+            unsigned d[4][2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) v[p] = acc[i][j][4 * q + p];
+                if (EPI == HS_FWD) {
+                    const float4 b = bias4[j][q];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) v[p] = fmaxf(v[p] + (p == 0 ? b.x : p == 1 ? b.y : p == 2 ? b.z : b.w), floor_v);
+                }
+                d[q][0] = pack_bf16(v[0], v[1]); d[q][1] = pack_bf16(v[2], v[3]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int qq = 2 * u;
+                const auto sx = __builtin_amdgcn_permlane32_swap(d[qq][0], d[qq + 1][0], false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(d[qq][1], d[qq + 1][1], false, false);
+                uint4 o = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                if (EPI == HS_DX && g.aux) {
+                    auto keep = [](unsigned a) {      // per bf16 half: 0xffff where the activation is > 0 (relu'), else 0
+                        const unsigned lo = (int)(short)(a & 0xffffu) > 0 ? 0xffffu : 0u;
+                        const unsigned hi = (int)a > 0xffff ? 0xffff0000u : 0u;
+                        return lo | hi;
+                    };
+                    o.x &= keep(mask[u].x); o.y &= keep(mask[u].y); o.z &= keep(mask[u].z); o.w &= keep(mask[u].w);
+                }
+                if (row_ok) *reinterpret_cast<uint4*>(g.C + rowoff + nj + 16 * u + 8 * h) = o;
+            }
+        }
+    }
+}
+
+// ---- dW|db ------------------------------------------------------------------------------------------------------------
+struct HsDwArgs {
+    const __bf16* X; const __bf16* dY; float* slab;   // X [rows, M] (ldx), dY [rows, N] (ldy), slab[split][(M + 1) x N]
+    int rows, M, N, ldx, ldy, rows_per_split; long long slab_stride;
+    int tiles_m, tiles_n;
+};
+
+// LDS image of a BK-row(k) x 128-feature tile: 256-byte rows, 16-byte chunk ch of row k at chunk position
+// ch ^ (((k & 3) << 2) | ((k >> 2) & 3)): the 32 lanes of a ds_read_b64_tr_b16 half (4 k-rows x 2 blocks of 16
+// features) then cover the 256-byte bank row exactly.
+template <int BK, int NS>
+__global__ __launch_bounds__(256) void hs_tn_kernel(const HsDwArgs g) {
+    constexpr int BM = 128, BN = 128, T_BYTES = BK * 256, BUF = 2 * T_BYTES;
+    constexpr int PASSES = BK / 16, P = 2 * PASSES;           // staging passes per operand tile; loads per k-tile and wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned tiles = g.tiles_m * g.tiles_n, nb = gridDim.x;
+    unsigned id = blockIdx.x;
+    if (nb % 8 == 0) id = (id % 8) * (nb / 8) + id / 8;        // the tiles of one split run on one XCD: they share X / dY rows
+    const int split = id / tiles, tile = id % tiles;
+    const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = split * g.rows_per_split, kend = min(g.rows, kbeg + g.rows_per_split);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+
+    // staging: 16 BK chunks per tile; position p -> k-row p >> 4, chunk slot p & 15
+    int a_col[PASSES], b_col[PASSES], s_row[PASSES];
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+        const int p = i * 256 + t, row = p >> 4, ch = (p & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        s_row[i] = row;
+        a_col[i] = min(m0 + ch * 8, g.M - 8);        // a partial last tile re-reads valid columns; those outputs are not stored
+        b_col[i] = min(n0 + ch * 8, g.N - 8);
+    }
+    auto stage = [&](int k0, int slot) {
+        char* base = smem + slot * BUF;
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const long long krow = min(k0 + s_row[i], g.rows - 1);
+            glds16(g.X + krow * g.ldx + a_col[i], base + (i * 256 + wv * 64) * 16);
+            glds16(g.dY + krow * g.ldy + b_col[i], base + T_BYTES + (i * 256 + wv * 64) * 16);
+        }
+    };
+    // transposed fragment reads: lane 4 q + p of a 16-lane group addresses k-row q, features 4 p .. 4 p + 3 of its block;
+    // the group receives features block + (lane & 15), four consecutive k each
+    const int h = lane >> 5, g16 = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
+    int a_addr[2][2], b_addr[2][2];                 // [fragment i / j][u: k rows 4 u .. 4 u + 3 of the lane half's 8]
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int krow = 8 * h + 4 * u + q, xr = (q << 2) | ((2 * h + u) & 3);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mcol = wm * 64 + i * 32 + 16 * g16 + 4 * p;
+            a_addr[i][u] = krow * 256 + (((mcol >> 3) ^ xr) << 4) + ((mcol >> 2) & 1) * 8;
+            const int ncol = wn * 64 + i * 32 + 16 * g16 + 4 * p;
+            b_addr[i][u] = krow * 256 + (((ncol >> 3) ^ xr) << 4) + ((ncol >> 2) & 1) * 8 + T_BYTES;
+        }
+    }
+    f32x16 acc[2][2], accb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; accb[i][r] = 0.f; }
+    }
+    const bool do_bias = tm == 0 && wm == 0;         // wave-uniform
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+    auto tr_read = [&](int addr) {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(smem + addr));
+    };
+    const int nt = (kend - kbeg + BK - 1) / BK;
+#pragma unroll
+    for (int qq = 0; qq < NS - 1; ++qq) if (qq < nt) stage(kbeg + qq * BK, qq);
+    int slot = 0, fill = NS - 1;
+    for (int kt = 0; kt < nt; ++kt) {
+        wait_tiles<P, NS - 2>(min(NS - 2, nt - 1 - kt));
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nt) stage(kbeg + (kt + NS - 1) * BK, fill);
+        const int boff = slot * BUF;
+        const int valid = kend - (kbeg + kt * BK);
+        if (valid < BK) {                           // last k-tile of the batch: rows past the end must contribute zero
+            for (int o = t * 16; o < BUF; o += 256 * 16)
+                if (((o & (T_BYTES - 1)) >> 8) >= valid) *reinterpret_cast<uint4*>(smem + boff + o) = make_uint4(0, 0, 0, 0);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bf16x4 a0 = tr_read(boff + a_addr[i][0] + s * 4096), a1 = tr_read(boff + a_addr[i][1] + s * 4096);
+                const bf16x4 b0 = tr_read(boff + b_addr[i][0] + s * 4096), b1 = tr_read(boff + b_addr[i][1] + s * 4096);
+                fa[i] = bf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                fb[i] = bf16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) accb[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fb[j], accb[j], 0, 0, 0);
+            }
+        }
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        fill = fill + 1 == NS ? 0 : fill + 1;
+    }
+    // ---- slab store: register r of tile (i, j) = G[m0 + 64 wm + 32 i + (r & 3) + 8 (r >> 2) + 4 h][n0 + 64 wn + 32 j + (lane & 31)]
+    float* C = g.slab + (long long)split * g.slab_stride;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (n >= g.N) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < g.M) C[(long long)m * g.N + n] = acc[i][j][r];
+            }
+        if (do_bias && h == 0) C[(long long)g.M * g.N + n] = accb[j][0];      // every row of 1 . dY is the column sum
+    }
+}
+
+// ---- bf16 copies of the wide layers' kernels ------------------------------------------------------------------------
+struct CvtArgs {
+    int n; int K[24], N[24]; long long w_off[24], out_off[24];     // out: W as stored [K, N], then W^T [N, K] (bf16 elements)
+};
+__global__ __launch_bounds__(256) void cvt_w_kernel(const float* __restrict__ params, __bf16* __restrict__ out, const CvtArgs a) {
+    __shared__ float tile[64][65];
+    const int l = blockIdx.y, K = a.K[l], N = a.N[l];
+    const int tn = N / 64, tk = K / 64;
+    if ((int)blockIdx.x >= tn * tk) return;
+    const int k0 = (blockIdx.x / tn) * 64, n0 = (blockIdx.x % tn) * 64;
+    const float* w = params + a.w_off[l];
+    __bf16* wb = out + a.out_off[l];
+    __bf16* wt = wb + (long long)K * N;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const float v = w[(long long)(k0 + r) * N + n0 + tx];
+        tile[r][tx] = v;
+        wb[(long long)(k0 + r) * N + n0 + tx] = (__bf16)v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) wt[(long long)(n0 + r) * K + k0 + tx] = (__bf16)tile[tx][r];
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------------------------
+// Tile / ring variants (tools/hs_tune.py times them on the box through vaek_debug_hs_gemm; g_hs_variant_* pick the default).
+typedef void (*HsNtKernel)(const HsArgs);
+struct HsNtVariant { HsNtKernel fwd, dx; int bm, bn, nth; size_t lds; const char* name; };
+#define HS_NT(BM, BN, WM, WN, BK, NS) \
+    {hs_nt_kernel<HS_FWD, BM, BN, WM, WN, BK, NS>, hs_nt_kernel<HS_DX, BM, BN, WM, WN, BK, NS>, BM, BN, 64 * WM * WN, \
+     (size_t)NS * (BM + BN) * 2 * BK, #BM "x" #BN "x" #BK " ring" #NS}
+static const HsNtVariant kNt[] = {
+    HS_NT(128, 128, 2, 2, 64, 2),      // 0: one tile of prefetch, 64 KB, two workgroups per CU (the first version)
+    HS_NT(128, 128, 2, 2, 32, 5),      // 1: 16 KB stages, four in flight, 80 KB, two workgroups per CU
+    HS_NT(128, 128, 2, 2, 64, 4),      // 2: 32 KB stages, three in flight, 128 KB, one workgroup per CU
+    HS_NT(256, 128, 4, 2, 64, 3),      // 3: 48 KB stages, two in flight, 144 KB, 8 waves
+    HS_NT(256, 128, 4, 2, 32, 6),      // 4: 24 KB stages, five in flight, 144 KB, 8 waves
+    HS_NT(128, 128, 2, 2, 32, 4),      // 5: 16 KB stages, three in flight, 64 KB, two workgroups per CU
+    HS_NT(128, 128, 2, 2, 32, 3),      // 6: 48 KB: three workgroups per CU
+};
+constexpr int kNtCount = sizeof(kNt) / sizeof(kNt[0]);
+typedef void (*HsTnKernel)(const HsDwArgs);
+struct HsTnVariant { HsTnKernel fn; size_t lds; const char* name; };
+static const HsTnVariant kTn[] = {
+    {hs_tn_kernel<64, 2>, 2 * 2 * 64 * 256, "128x128x64 ring2"},      // 0: the first version
+    {hs_tn_kernel<32, 5>, 5 * 2 * 32 * 256, "128x128x32 ring5"},      // 1
+    {hs_tn_kernel<64, 4>, 4 * 2 * 64 * 256, "128x128x64 ring4"},      // 2: one workgroup per CU
+    {hs_tn_kernel<32, 4>, 4 * 2 * 32 * 256, "128x128x32 ring4"},      // 3
+    {hs_tn_kernel<32, 3>, 3 * 2 * 32 * 256, "128x128x32 ring3"},      // 4: three workgroups per CU
+};
+constexpr int kTnCount = sizeof(kTn) / sizeof(kTn[0]);
+int g_hs_variant_nt = 1, g_hs_variant_tn = 1;
+
+template <int EPI>
+static int hs_launch_nt(const HsArgs& g, const char* label, hipStream_t st) {
+    if (g.M <= 0) return VAEK_OK;
+    if (g.K % 64 || g.N % 64 || g.lda % 8 || g.ldb % 8 || g.ldc % 8) { set_error("bf16-storage GEMM needs widths that are multiples of 64"); return VAEK_ERR_INVALID; }
+    const int vi = g_hs_variant_nt;
+    if (vi < 0 || vi >= kNtCount) { set_error("unknown bf16-storage GEMM variant %d", vi); return VAEK_ERR_INVALID; }
+    const HsNtVariant& v = kNt[vi];
+    const HsNtKernel fn = EPI == HS_FWD ? v.fwd : v.dx;
+    static thread_local bool attr_set[2][kNtCount] = {};
+    if (!attr_set[EPI][vi]) {
+        VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
+        attr_set[EPI][vi] = true;
+    }
+    const unsigned grid = (unsigned)(((g.M + v.bm - 1) / v.bm) * ((g.N + v.bn - 1) / v.bn));
+    ProfScope ps(label, st);
+    launch_k(ps, fn, dim3(grid), dim3(v.nth), v.lds, st, g);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+int launch_hs_fwd(const __bf16* x, const __bf16* wT, const float* b, __bf16* y, int rows, int n_in, int n_out, bool relu,
+                  hipStream_t st) {
+    HsArgs g{};
+    g.A = x; g.Bt = wT; g.C = y; g.M = rows; g.N = n_out; g.K = n_in; g.lda = n_in; g.ldb = n_in; g.ldc = n_out;
+    g.bias = b; g.relu = relu;
+    return hs_launch_nt<HS_FWD>(g, "gemm_bf16s_fwd", st);
+}
+// dX[rows, n_in] = (dY[rows, n_out] . W^T) * (x_post > 0); W as stored [n_in, n_out] is the k-contiguous Bt operand
+int launch_hs_dx(const __bf16* dy, const __bf16* w16, const __bf16* x_post, __bf16* dx, int rows, int n_in, int n_out,
+                 hipStream_t st) {
+    HsArgs g{};
+    g.A = dy; g.Bt = w16; g.C = dx; g.M = rows; g.N = n_in; g.K = n_out; g.lda = n_out; g.ldb = n_out; g.ldc = n_in;
+    g.aux = x_post;
+    return hs_launch_nt<HS_DX>(g, "gemm_bf16s_dx", st);
+}
+int launch_hs_dw(const __bf16* x, const __bf16* dy, float* slab0, int64_t slab_stride, int S, int rows_per_split, int rows,
+                 int n_in, int n_out, hipStream_t st) {
+    if (rows <= 0) return VAEK_OK;
+    if (n_in % 64 || n_out % 64 || rows_per_split % 64) { set_error("bf16-storage dW needs widths / splits that are multiples of 64"); return VAEK_ERR_INVALID; }
+    HsDwArgs g{};
+    g.X = x; g.dY = dy; g.slab = slab0; g.rows = rows; g.M = n_in; g.N = n_out; g.ldx = n_in; g.ldy = n_out;
+    g.rows_per_split = rows_per_split; g.slab_stride = slab_stride;
+    g.tiles_m = (n_in + 127) / 128; g.tiles_n = (n_out + 127) / 128;
+    const int vi = g_hs_variant_tn;
+    if (vi < 0 || vi >= kTnCount) { set_error("unknown bf16-storage dW variant %d", vi); return VAEK_ERR_INVALID; }
+    const HsTnVariant& v = kTn[vi];
+    static thread_local bool attr_set[kTnCount] = {};
+    if (!attr_set[vi]) {
+        VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
+        attr_set[vi] = true;
+    }
+    ProfScope ps("gemm_bf16s_dw", st);
+    launch_k(ps, v.fn, dim3((unsigned)(g.tiles_m * g.tiles_n * S)), dim3(256), v.lds, st, g);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+int launch_cvt_weights(const float* params, __bf16* out, const int* K, const int* N, const int64_t* w_off, const int64_t* out_off,
+                       int n, hipStream_t st) {
+    if (n <= 0) return VAEK_OK;
+    if (n > 24) { set_error("too many wide layers"); return VAEK_ERR_INVALID; }
+    CvtArgs a{};
+    a.n = n;
+    int maxt = 0;
+    for (int i = 0; i < n; ++i) {
+        a.K[i] = K[i]; a.N[i] = N[i]; a.w_off[i] = w_off[i]; a.out_off[i] = out_off[i];
+        maxt = std::max(maxt, (K[i] / 64) * (N[i] / 64));
+    }
+    ProfScope ps("cvt_weights_bf16", st);
+    launch_k(ps, cvt_w_kernel, dim3((unsigned)maxt, (unsigned)n), dim3(256), 0, st, params, out, a);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+}  // namespace vaek
+
+// Diagnostic hook (not part of include/vaek.h; tools/hs_tune.py): pick the tile / ring variant of the bf16-storage GEMMs
+// for this process (-1 keeps the current one) and report how many exist.
+extern "C" int vaek_debug_hs_variant(int nt, int tn, int* n_nt, int* n_tn) {
+    if (nt >= vaek::kNtCount || tn >= vaek::kTnCount) return VAEK_ERR_INVALID;
+    if (nt >= 0) vaek::g_hs_variant_nt = nt;
+    if (tn >= 0) vaek::g_hs_variant_tn = tn;
+    if (n_nt) *n_nt = vaek::kNtCount;
+    if (n_tn) *n_tn = vaek::kTnCount;
+    return VAEK_OK;
+}

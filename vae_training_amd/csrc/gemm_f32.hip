@@ -25,13 +25,25 @@ constexpr int NT = 256;      // BK (k-tile depth) is a template parameter: 16, o
 
 enum { EPI_FWD = 0, EPI_REPARAM = 1, EPI_DX = 2, EPI_DW = 3, EPI_ELBO = 4 };
 
+// Operand storage types: float everywhere on the f32 path; in the bf16-storage mode (gemm_bf16s.hip, api.hip) the
+// skinny first / last layer of a stack runs on THIS exact-f32 kernel with the hidden-side operand stored as bf16
+// (TA / TB: operands, TC: output, TX: the relu-mask source of the dX epilogue), converted while it is staged.
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 ld4<__bf16>(const __bf16* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+template <typename T> __device__ __forceinline__ bool vec4_aligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(T) - 1)) == 0; }
+
 struct GemmArgs {
-    const float* A; const float* B; float* C;
+    const void* A; const void* B; void* C;      // element types are the kernel's TA / TB / TC
     int M, N, K;              // logical dims, K = reduction
     int lda, ldb, ldc;
     int a_mem;                // A, m-contiguous mode: number of real m columns in memory (ones row at index a_mem)
     const float* bias; int relu;
-    const float* aux;         // DX: x_post [M, ldc]; REPARAM: z1 [M, ldc]
+    const void* aux;          // DX: x_post [M, ldc] (type TX); REPARAM: z1 [M, ldc]; ELBO: x [M, ldc] (float)
     float* C2;                // REPARAM: samples
     const float* lv;          // REPARAM: logvar_e [N]
     int accumulate;
@@ -44,8 +56,8 @@ struct GemmArgs {
 
 // Operand tile = T (mn) x BK (k) floats, staged k-major into LDS rows of T + 4 floats.
 // k-contiguous source p[mn*ld + k]: float4 unit u -> row u / (BK/4), k = 4 (u % (BK/4)); T*BK/4 units over 256 threads.
-template <int T, int BK>
-__device__ __forceinline__ void fetch_kcont(const float* __restrict__ p, int ld, int mn0, int MN, int k0, int kend,
+template <int T, int BK, typename E>
+__device__ __forceinline__ void fetch_kcont(const E* __restrict__ p, int ld, int mn0, int MN, int k0, int kend,
                                             bool vec_ok, float (&v)[(T * BK / 4 + NT - 1) / NT][4]) {
     constexpr int NU = (T * BK / 4 + NT - 1) / NT;
 #pragma unroll
@@ -55,13 +67,13 @@ __device__ __forceinline__ void fetch_kcont(const float* __restrict__ p, int ld,
         if (u >= T * BK / 4) continue;
         const int mn = mn0 + u / (BK / 4), k = k0 + (u % (BK / 4)) * 4;
         if (mn < MN) {
-            const float* q = p + (long long)mn * ld + k;
+            const E* q = p + (long long)mn * ld + k;
             if (vec_ok && k + 3 < kend) {
-                const float4 f = *reinterpret_cast<const float4*>(q);
+                const float4 f = ld4<E>(q);
                 v[i][0] = f.x; v[i][1] = f.y; v[i][2] = f.z; v[i][3] = f.w;
             } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) if (k + c < kend) v[i][c] = q[c];
+                for (int c = 0; c < 4; ++c) if (k + c < kend) v[i][c] = (float)q[c];
             }
         }
     }
@@ -79,8 +91,8 @@ __device__ __forceinline__ void store_kcont(float* s, const float (&v)[(T * BK /
 }
 // mn-contiguous source p[k*ld + mn]: float4 unit u -> k = u / (T/4), mn = 4 (u % (T/4)); mn == mem (only for the
 // augmented operand) reads as 1, mn > mem as 0.
-template <int T, int BK>
-__device__ __forceinline__ void fetch_mncont(const float* __restrict__ p, int ld, int mn0, int mem, bool aug, int k0,
+template <int T, int BK, typename E>
+__device__ __forceinline__ void fetch_mncont(const E* __restrict__ p, int ld, int mn0, int mem, bool aug, int k0,
                                              int kend, bool vec_ok, float (&v)[(T * BK / 4 + NT - 1) / NT][4]) {
     constexpr int NU = (T * BK / 4 + NT - 1) / NT;
 #pragma unroll
@@ -90,14 +102,14 @@ __device__ __forceinline__ void fetch_mncont(const float* __restrict__ p, int ld
         if (u >= T * BK / 4) continue;
         const int k = k0 + u / (T / 4), mn = mn0 + (u % (T / 4)) * 4;
         if (k < kend) {
-            const float* q = p + (long long)k * ld + mn;
+            const E* q = p + (long long)k * ld + mn;
             if (vec_ok && mn + 3 < mem) {
-                const float4 f = *reinterpret_cast<const float4*>(q);
+                const float4 f = ld4<E>(q);
                 v[i][0] = f.x; v[i][1] = f.y; v[i][2] = f.z; v[i][3] = f.w;
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    if (mn + c < mem) v[i][c] = q[c];
+                    if (mn + c < mem) v[i][c] = (float)q[c];
                     else if (aug && mn + c == mem) v[i][c] = 1.f;
                 }
             }
@@ -119,33 +131,35 @@ __device__ __forceinline__ void store_mncont(float* s, const float (&v)[(T * BK 
 // hipcc merges a conditionally loaded value into its zero-initialised registers INSIDE the branch, i.e. it waits for each
 // load where it is issued -- the "prefetch under the MFMAs" was a chain of exposed latencies.  A tile that lies fully
 // inside the operand (almost all of them) takes these.
-template <int T, int BK>
-__device__ __forceinline__ void fetch_kcont_full(const float* __restrict__ p, int ld, int mn0, int k0,
+template <int T, int BK, typename E>
+__device__ __forceinline__ void fetch_kcont_full(const E* __restrict__ p, int ld, int mn0, int k0,
                                                  float (&v)[(T * BK / 4 + NT - 1) / NT][4]) {
     constexpr int NU = (T * BK / 4 + NT - 1) / NT;
     static_assert(T * BK / 4 % NT == 0, "whole passes");
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
         const int u = threadIdx.x + i * NT;
-        const float4 f = *reinterpret_cast<const float4*>(p + (long long)(mn0 + u / (BK / 4)) * ld + k0 + (u % (BK / 4)) * 4);
+        const float4 f = ld4<E>(p + (long long)(mn0 + u / (BK / 4)) * ld + k0 + (u % (BK / 4)) * 4);
         v[i][0] = f.x; v[i][1] = f.y; v[i][2] = f.z; v[i][3] = f.w;
     }
 }
-template <int T, int BK>
-__device__ __forceinline__ void fetch_mncont_full(const float* __restrict__ p, int ld, int mn0, int k0,
+template <int T, int BK, typename E>
+__device__ __forceinline__ void fetch_mncont_full(const E* __restrict__ p, int ld, int mn0, int k0,
                                                   float (&v)[(T * BK / 4 + NT - 1) / NT][4]) {
     constexpr int NU = (T * BK / 4 + NT - 1) / NT;
     static_assert(T * BK / 4 % NT == 0, "whole passes");
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
         const int u = threadIdx.x + i * NT;
-        const float4 f = *reinterpret_cast<const float4*>(p + (long long)(k0 + u / (T / 4)) * ld + mn0 + (u % (T / 4)) * 4);
+        const float4 f = ld4<E>(p + (long long)(k0 + u / (T / 4)) * ld + mn0 + (u % (T / 4)) * 4);
         v[i][0] = f.x; v[i][1] = f.y; v[i][2] = f.z; v[i][3] = f.w;
     }
 }
 
-template <bool A_KCONT, bool B_KCONT, int EPI, int WM, int WN, int BK, int TM = 1, int TN = 1>
+template <typename TA, typename TB, typename TC, typename TX, bool A_KCONT, bool B_KCONT, int EPI, int WM, int WN, int BK, int TM = 1, int TN = 1>
 __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
+    const TA* const gA = static_cast<const TA*>(g.A);
+    const TB* const gB = static_cast<const TB*>(g.B);
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, SA = BM + 4, SB = BN + 4;
     __shared__ __attribute__((aligned(16))) float As[BK * SA];
     __shared__ __attribute__((aligned(16))) float Bs[BK * SB];
@@ -168,10 +182,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
         kbeg = bz * g.k_per_split;
         kend = min(g.K, kbeg + g.k_per_split);
     }
-    const bool a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) &&
-                       (A_KCONT ? (kbeg % 4 == 0) : true);
-    const bool b_vec = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0) &&
-                       (B_KCONT ? (kbeg % 4 == 0) : true);
+    const bool a_vec = (g.lda % 4 == 0) && vec4_aligned<TA>(g.A) && (A_KCONT ? (kbeg % 4 == 0) : true);
+    const bool b_vec = (g.ldb % 4 == 0) && vec4_aligned<TB>(g.B) && (B_KCONT ? (kbeg % 4 == 0) : true);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     f32x16 acc[TM][TN];
@@ -192,12 +204,12 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
     const bool b_in = b_vec && n0 + BN <= g.N;
     auto fetch = [&](int k0, int set) {
         const bool k_in = k0 + BK <= kend;                 // uniform: a scalar branch
-        if (a_in && k_in) { if (A_KCONT) fetch_kcont_full<BM, BK>(g.A, g.lda, m0, k0, ra[set]); else fetch_mncont_full<BM, BK>(g.A, g.lda, m0, k0, ra[set]); }
-        else if (A_KCONT) fetch_kcont<BM, BK>(g.A, g.lda, m0, g.M, k0, kend, a_vec, ra[set]);
-        else fetch_mncont<BM, BK>(g.A, g.lda, m0, g.a_mem, EPI == EPI_DW, k0, kend, a_vec, ra[set]);
-        if (b_in && k_in) { if (B_KCONT) fetch_kcont_full<BN, BK>(g.B, g.ldb, n0, k0, rb[set]); else fetch_mncont_full<BN, BK>(g.B, g.ldb, n0, k0, rb[set]); }
-        else if (B_KCONT) fetch_kcont<BN, BK>(g.B, g.ldb, n0, g.N, k0, kend, b_vec, rb[set]);
-        else fetch_mncont<BN, BK>(g.B, g.ldb, n0, g.N, false, k0, kend, b_vec, rb[set]);
+        if (a_in && k_in) { if (A_KCONT) fetch_kcont_full<BM, BK>(gA, g.lda, m0, k0, ra[set]); else fetch_mncont_full<BM, BK>(gA, g.lda, m0, k0, ra[set]); }
+        else if (A_KCONT) fetch_kcont<BM, BK>(gA, g.lda, m0, g.M, k0, kend, a_vec, ra[set]);
+        else fetch_mncont<BM, BK>(gA, g.lda, m0, g.a_mem, EPI == EPI_DW, k0, kend, a_vec, ra[set]);
+        if (b_in && k_in) { if (B_KCONT) fetch_kcont_full<BN, BK>(gB, g.ldb, n0, k0, rb[set]); else fetch_mncont_full<BN, BK>(gB, g.ldb, n0, k0, rb[set]); }
+        else if (B_KCONT) fetch_kcont<BN, BK>(gB, g.ldb, n0, g.N, k0, kend, b_vec, rb[set]);
+        else fetch_mncont<BN, BK>(gB, g.ldb, n0, g.N, false, k0, kend, b_vec, rb[set]);
     };
     auto stage_and_multiply = [&](int k0, int set) {
         __syncthreads();                       // previous tile fully consumed
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
                     const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const bool in = col < g.N && row < g.M;
                     const long long o = in ? (long long)row * g.ldc + col : 0;
-                    auxv[kAux ? i : 0][kAux ? jn : 0][r] = g.aux[o];
+                    auxv[kAux ? i : 0][kAux ? jn : 0][r] = EPI == EPI_DX ? (float)static_cast<const TX*>(g.aux)[o] : static_cast<const float*>(g.aux)[o];
                     if (EPI == EPI_ELBO) aux2v[EPI == EPI_ELBO ? i : 0][EPI == EPI_ELBO ? jn : 0][r] = g.aux2[o];
                 }
         }
@@ -262,7 +274,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
         float bias = 0.f, sdev = 0.f;
         if (EPI == EPI_FWD || EPI == EPI_REPARAM || EPI == EPI_ELBO) bias = g.bias ? g.bias[col] : 0.f;
         if (EPI == EPI_REPARAM) sdev = expf(0.5f * g.lv[col]);
-        float* C = g.C;
+        TC* C = static_cast<TC*>(g.C);
         if (EPI == EPI_DW) C += (long long)bz * g.slab_stride;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -276,24 +288,24 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
                 if (EPI == EPI_FWD) {
                     v += bias;
                     if (g.relu) v = fmaxf(v, 0.f);
-                    C[o] = v;
+                    C[o] = (TC)v;
                 } else if (EPI == EPI_REPARAM) {
                     v += bias;
-                    C[o] = v;
+                    C[o] = (TC)v;
                     g.C2[o] = v + sdev * ax;
                 } else if (EPI == EPI_DX) {
                     if (g.relu) v = ax > 0.f ? v : 0.f;
-                    if (g.accumulate) v += C[o];
-                    C[o] = v;
+                    if (g.accumulate) v += (float)C[o];
+                    C[o] = (TC)v;
                 } else if (EPI == EPI_ELBO) {
                     const float z = aux2v[EPI == EPI_ELBO ? i : 0][EPI == EPI_ELBO ? jn : 0][r];
                     const float rr = (v + bias) + e_sigma * z - ax;              // x_hat - x, x_hat = y + z2 e^{eps/2}
                     const float q = rr * rr * e_inv_var;
                     e_mse += 0.5f * q;
                     e_deps += -0.5f * q + 0.5f * e_sigma * z * rr * e_inv_var;
-                    C[o] = rr * e_dscale;
+                    C[o] = (TC)(rr * e_dscale);
                 } else {
-                    C[o] = v;
+                    C[o] = (TC)v;
                 }
             }
         }
@@ -314,7 +326,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
 
 static thread_local int g_last_bm = 0, g_last_nbx = 0;      // tile rows / tile columns of the last launch (ELBO partials)
 
-template <bool A_KCONT, bool B_KCONT, int EPI, int WM, int WN, int BK, int TM = 1, int TN = 1>
+template <typename TA, typename TB, typename TC, typename TX, bool A_KCONT, bool B_KCONT, int EPI, int WM, int WN, int BK, int TM = 1, int TN = 1>
 static int launch_shape(const GemmArgs& g, int splits, hipStream_t st) {
     // the 128 x 128 register-blocked shape carries its own label, so that tests can assert it ran (tests/test_gpu_wide.py)
     constexpr bool BIG = TM == 2 && TN == 2;
@@ -327,17 +339,18 @@ static int launch_shape(const GemmArgs& g, int splits, hipStream_t st) {
         return VAEK_ERR_INVALID;
     }
     g_last_bm = 32 * WM * TM; g_last_nbx = (int)grid.x;
-    launch_k(ps, (gemm_f32_kernel<A_KCONT, B_KCONT, EPI, WM, WN, BK, TM, TN>), grid, dim3(NT), 0, st, g);
+    launch_k(ps, (gemm_f32_kernel<TA, TB, TC, TX, A_KCONT, B_KCONT, EPI, WM, WN, BK, TM, TN>), grid, dim3(NT), 0, st, g);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
 }
 
-template <bool A_KCONT, bool B_KCONT, int EPI>
+template <bool A_KCONT, bool B_KCONT, int EPI, typename TA = float, typename TB = float, typename TC = float, typename TX = float>
 static int launch(const GemmArgs& g, int splits, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return VAEK_OK;
+    constexpr bool kAllF32 = sizeof(TA) == 4 && sizeof(TB) == 4 && sizeof(TC) == 4 && sizeof(TX) == 4;
     // skinny shapes stream a long K past a small output: a 32-deep k-tile halves their barriers per byte
-    if (g.N <= 32) return launch_shape<A_KCONT, B_KCONT, EPI, 4, 1, 32>(g, splits, st);     // skinny output: 128 x 32
-    if (g.M <= 32) return launch_shape<A_KCONT, B_KCONT, EPI, 1, 4, 32>(g, splits, st);     // skinny M:      32 x 128
+    if (g.N <= 32) return launch_shape<TA, TB, TC, TX, A_KCONT, B_KCONT, EPI, 4, 1, 32>(g, splits, st);     // skinny output: 128 x 32
+    if (g.M <= 32) return launch_shape<TA, TB, TC, TX, A_KCONT, B_KCONT, EPI, 1, 4, 32>(g, splits, st);     // skinny M:      32 x 128
     // wide layers: 128 x 128 (each wave 2 x 2 MFMA tiles) halves the operand bytes pulled through L2 per flop -- at
     // 64 x 64 the 512-wide layers of C3 need ~7 TB/s of L2 -> LDS traffic to keep the f32 matrix pipe busy (C3 forward
     // 1.75 -> 1.53 ms, dX 2.22 -> 1.93 ms, dW|db 2.23 -> 2.02 ms with the split count raised to match, api.hip).  Only
@@ -351,9 +364,11 @@ static int launch(const GemmArgs& g, int splits, hipStream_t st) {
     // pre-transposed copy of W so that its B operand stages with 16-byte LDS stores like the forward's (no change),
     // (two register-staged k-tiles in flight lost 7 % while the fetch was serialised; with the full-tile fetch they win for
     // the tall-skinny forward / dX shape -- C4 0.966 -> 0.933 ms -- and still lose slightly for the dW shapes).
-    if (g.M >= 128 && g.N >= 128 && g.K >= 128 && (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * splits >= 512)
-        return launch_shape<A_KCONT, B_KCONT, EPI, 2, 2, 32, 2, 2>(g, splits, st);
-    return launch_shape<A_KCONT, B_KCONT, EPI, 2, 2, 16>(g, splits, st);                    // 64 x 64
+    // (the bf16-storage variants exist for the skinny first / last layers only: they skip the 128 x 128 instantiation)
+    if constexpr (kAllF32)
+        if (g.M >= 128 && g.N >= 128 && g.K >= 128 && (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * splits >= 512)
+            return launch_shape<TA, TB, TC, TX, A_KCONT, B_KCONT, EPI, 2, 2, 32, 2, 2>(g, splits, st);
+    return launch_shape<TA, TB, TC, TX, A_KCONT, B_KCONT, EPI, 2, 2, 16>(g, splits, st);                    // 64 x 64
 }
 
 int launch_dense_fwd(const float* x, const float* w, const float* b, float* y, int rows, int n_in,
@@ -405,6 +420,74 @@ int launch_dense_bwd_dw(const float* x, const float* dy, float* slab0, int64_t s
     g.lda = n_in; g.ldb = n_out; g.ldc = n_out; g.a_mem = n_in;
     g.k_per_split = rows_per_split; g.slab_stride = slab_stride;
     return launch<false, false, EPI_DW>(g, S, st);
+}
+
+// ---- bf16-storage mode (api.hip, gemm_bf16s.hip): the first / last layer of a stack on the exact f32 kernel with its
+// hidden-side operand stored as bf16 ------------------------------------------------------------------------------------
+// first layer forward: x f32 [rows, n_in] -> relu(.) as bf16 [rows, n_out]
+int launch_dense_fwd_out16(const float* x, const float* w, const float* b, __bf16* y, int rows, int n_in, int n_out, bool relu,
+                           hipStream_t st) {
+    GemmArgs g{};
+    g.A = x; g.B = w; g.C = y; g.M = rows; g.N = n_out; g.K = n_in;
+    g.lda = n_in; g.ldb = n_out; g.ldc = n_out; g.bias = b; g.relu = relu;
+    return launch<true, false, EPI_FWD, float, float, __bf16>(g, 1, st);
+}
+// last layer forward from a bf16 hidden activation: plain / reparameterisation / ELBO epilogues (f32 out)
+int launch_dense_fwd_in16(const __bf16* x, const float* w, const float* b, float* y, int rows, int n_in, int n_out, hipStream_t st) {
+    GemmArgs g{};
+    g.A = x; g.B = w; g.C = y; g.M = rows; g.N = n_out; g.K = n_in;
+    g.lda = n_in; g.ldb = n_out; g.ldc = n_out; g.bias = b; g.relu = 0;
+    return launch<true, false, EPI_FWD, __bf16>(g, 1, st);
+}
+int launch_dense_fwd_reparam_in16(const __bf16* x, const float* w, const float* b, float* mu, float* samples, const float* z1,
+                                  const float* lv, int rows, int n_in, int n_out, hipStream_t st) {
+    GemmArgs g{};
+    g.A = x; g.B = w; g.C = mu; g.C2 = samples; g.aux = z1; g.lv = lv;
+    g.M = rows; g.N = n_out; g.K = n_in; g.lda = n_in; g.ldb = n_out; g.ldc = n_out; g.bias = b;
+    return launch<true, false, EPI_REPARAM, __bf16>(g, 1, st);
+}
+int launch_dense_fwd_elbo_in16(const __bf16* h, const float* w, const float* b, float* d_out, const float* x, const float* z2,
+                               const float* eps_param, float eps_cli, float inv_bt, float* part, int rows, int n_in, int n_out,
+                               int* bm, int* nbx, hipStream_t st) {
+    GemmArgs g{};
+    g.A = h; g.B = w; g.C = d_out; g.M = rows; g.N = n_out; g.K = n_in;
+    g.lda = n_in; g.ldb = n_out; g.ldc = n_out; g.bias = b;
+    g.aux = x; g.aux2 = z2; g.part = part; g.eps_param = eps_param; g.eps_cli = eps_cli; g.inv_bt = inv_bt;
+    const int rc = launch<true, false, EPI_ELBO, __bf16>(g, 1, st);
+    *bm = g_last_bm; *nbx = g_last_nbx;
+    return rc;
+}
+// last layer backward: dX as bf16 [rows, n_in] with the relu mask taken from the bf16 activation x_post
+int launch_dense_bwd_dx_out16(const float* dy, const float* w, const __bf16* x_post, __bf16* dx, int rows, int n_in, int n_out,
+                              bool accumulate, hipStream_t st) {
+    GemmArgs g{};
+    g.A = dy; g.B = w; g.C = dx; g.M = rows; g.N = n_in; g.K = n_out;
+    g.lda = n_out; g.ldb = n_out; g.ldc = n_in; g.aux = x_post; g.relu = 1; g.accumulate = accumulate;
+    return launch<true, true, EPI_DX, float, float, __bf16, __bf16>(g, 1, st);
+}
+// last layer dW|db: [X | 1]^T dY with X = bf16 hidden activation
+int launch_dense_bwd_dw_x16(const __bf16* x, const float* dy, float* slab0, int64_t slab_stride, int S, int rows_per_split,
+                            int rows, int n_in, int n_out, hipStream_t st) {
+    GemmArgs g{};
+    g.A = x; g.B = dy; g.C = slab0; g.M = n_in + 1; g.N = n_out; g.K = rows;
+    g.lda = n_in; g.ldb = n_out; g.ldc = n_out; g.a_mem = n_in; g.k_per_split = rows_per_split; g.slab_stride = slab_stride;
+    return launch<false, false, EPI_DW, __bf16>(g, S, st);
+}
+// first layer dW|db: [X | 1]^T dY with dY = bf16 hidden gradient
+int launch_dense_bwd_dw_dy16(const float* x, const __bf16* dy, float* slab0, int64_t slab_stride, int S, int rows_per_split,
+                             int rows, int n_in, int n_out, hipStream_t st) {
+    GemmArgs g{};
+    g.A = x; g.B = dy; g.C = slab0; g.M = n_in + 1; g.N = n_out; g.K = rows;
+    g.lda = n_in; g.ldb = n_out; g.ldc = n_out; g.a_mem = n_in; g.k_per_split = rows_per_split; g.slab_stride = slab_stride;
+    return launch<false, false, EPI_DW, float, __bf16>(g, S, st);
+}
+// first layer dX (the decoder's first layer: d samples, f32) from a bf16 hidden gradient
+int launch_dense_bwd_dx_in16(const __bf16* dy, const float* w, float* dx, int rows, int n_in, int n_out, bool accumulate,
+                             hipStream_t st) {
+    GemmArgs g{};
+    g.A = dy; g.B = w; g.C = dx; g.M = rows; g.N = n_in; g.K = n_out;
+    g.lda = n_out; g.ldb = n_out; g.ldc = n_in; g.aux = nullptr; g.relu = 0; g.accumulate = accumulate;
+    return launch<true, true, EPI_DX, __bf16>(g, 1, st);
 }
 
 }  // namespace vaek

@@ -39,8 +39,13 @@ struct Layer {
 
 struct Net {
     std::vector<Layer> layers;
-    // workspace byte offsets of each layer's OUTPUT activation [B, n_out] (float32)
+    // workspace byte offsets of each layer's OUTPUT activation [B, n_out] (float32; bf16 for the hidden layers of a b16 net)
     std::vector<size_t> act_off;
+    // bf16-storage mode (dtype = VAEK_BF16, >= 2 hidden layers, every hidden width a multiple of 64): hidden activations
+    // and gradients are bf16; layer 0 and the last layer run the exact f32 kernel with one bf16-stored side, the layers in
+    // between gemm_bf16s.hip.  wb_off[i]: element offset of layer i's bf16 kernel copies (W, then W^T) in ws_wb16.
+    bool b16 = false;
+    std::vector<int64_t> wb_off;
 };
 
 // Event-pair pool for vaek_profile_*: one pair per kernel launch while enabled.
@@ -95,7 +100,7 @@ struct vaek_ctx {
     int S, rows_per_split, Se, rows_per_esplit;
     bool fused;                      // fused small-model path available and selected
     // workspace layout (bytes)
-    size_t ws_samples, ws_dsamp, ws_gbuf0, ws_gbuf1, ws_slabs, ws_epart, ws_rpart, ws_eblk, ws_fused, ws_total;
+    size_t ws_samples, ws_dsamp, ws_gbuf0, ws_gbuf1, ws_slabs, ws_epart, ws_rpart, ws_eblk, ws_fused, ws_wb16, ws_total;
     int max_width;
     int n_cu;
     vaek::Comm comm;
@@ -128,6 +133,34 @@ int launch_dense_bwd_dx_bf16(const float* dy, const float* w, const float* x_pos
                              int n_out, bool relu, bool accumulate, hipStream_t st);
 int launch_dense_bwd_dw_bf16(const float* x, const float* dy, float* slab0, int64_t slab_stride, int S, int rows_per_split,
                              int rows, int n_in, int n_out, hipStream_t st);
+
+// ---- bf16-STORAGE mode (hidden activations / gradients kept as bf16 in HBM) ------------------------------------------
+// gemm_f32.hip: the skinny first / last layer of a stack on the exact f32 kernel, hidden-side operand stored as bf16
+int launch_dense_fwd_out16(const float* x, const float* w, const float* b, __bf16* y, int rows, int n_in, int n_out, bool relu,
+                           hipStream_t st);
+int launch_dense_fwd_in16(const __bf16* x, const float* w, const float* b, float* y, int rows, int n_in, int n_out, hipStream_t st);
+int launch_dense_fwd_reparam_in16(const __bf16* x, const float* w, const float* b, float* mu, float* samples, const float* z1,
+                                  const float* lv, int rows, int n_in, int n_out, hipStream_t st);
+int launch_dense_fwd_elbo_in16(const __bf16* h, const float* w, const float* b, float* d_out, const float* x, const float* z2,
+                               const float* eps_param, float eps_cli, float inv_bt, float* part, int rows, int n_in, int n_out,
+                               int* bm, int* nbx, hipStream_t st);
+int launch_dense_bwd_dx_out16(const float* dy, const float* w, const __bf16* x_post, __bf16* dx, int rows, int n_in, int n_out,
+                              bool accumulate, hipStream_t st);
+int launch_dense_bwd_dw_x16(const __bf16* x, const float* dy, float* slab0, int64_t slab_stride, int S, int rows_per_split,
+                            int rows, int n_in, int n_out, hipStream_t st);
+int launch_dense_bwd_dw_dy16(const float* x, const __bf16* dy, float* slab0, int64_t slab_stride, int S, int rows_per_split,
+                             int rows, int n_in, int n_out, hipStream_t st);
+int launch_dense_bwd_dx_in16(const __bf16* dy, const float* w, float* dx, int rows, int n_in, int n_out, bool accumulate,
+                             hipStream_t st);
+// gemm_bf16s.hip: the wide hidden -> hidden layers, bf16 in / bf16 out on v_mfma_f32_32x32x16_bf16
+int launch_hs_fwd(const __bf16* x, const __bf16* wT, const float* b, __bf16* y, int rows, int n_in, int n_out, bool relu,
+                  hipStream_t st);
+int launch_hs_dx(const __bf16* dy, const __bf16* w16, const __bf16* x_post, __bf16* dx, int rows, int n_in, int n_out,
+                 hipStream_t st);
+int launch_hs_dw(const __bf16* x, const __bf16* dy, float* slab0, int64_t slab_stride, int S, int rows_per_split, int rows,
+                 int n_in, int n_out, hipStream_t st);
+int launch_cvt_weights(const float* params, __bf16* out, const int* K, const int* N, const int64_t* w_off, const int64_t* out_off,
+                       int n, hipStream_t st);
 
 // ---- elbo.hip -----------------------------------------------------------------------------
 struct ElboArgs {
