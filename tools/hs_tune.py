@@ -12,6 +12,7 @@ from bench import WORKLOADS, init_params_flat, make_batches, data_dim  # noqa: E
 from vae_training_amd.engine import Engine  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+SINGLE = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else None      # profile one (nt, tn) pair only
 w = WORKLOADS["C3"]
 D, L = data_dim(w), w["L"]
 eng = Engine(B, D, L, w["enc"], w["dec"], w["eps"], w["tdv"], False, dtype="bf16")
@@ -37,11 +38,15 @@ def run(nt, tn, reps=6):
     return g, {k: v["total_ms"] / v["count"] * 1e3 for k, v in rep.items()}, sum(v["total_ms"] for v in rep.values()) / reps * 1e3
 
 
+if SINGLE is not None:
+    _, t0, tot0 = run(*SINGLE, reps=3)
+    print(f"variant nt={SINGLE[0]} tn={SINGLE[1]}: step kernels {tot0:.0f} us; per launch:", {k: round(v, 1) for k, v in t0.items()})
+    sys.exit(0)
 ref, t0, tot0 = run(0, 0)
 print(f"variant nt=0 tn=0: step kernels {tot0:.0f} us; per launch:", {k: round(v, 1) for k, v in t0.items() if "bf16s" in k})
-for nt in range(1, n_nt.value):
+for nt in ([int(a) for a in os.environ["HS_NT"].split(",")] if os.environ.get("HS_NT") else range(1, n_nt.value)):
     g, t, tot = run(nt, 0)
     print(f"nt={nt}: fwd {t['gemm_bf16s_fwd']:.1f} dx {t['gemm_bf16s_dx']:.1f} us   identical={torch.equal(g, ref)}", flush=True)
-for tn in range(1, n_tn.value):
+for tn in ([int(a) for a in os.environ["HS_TN"].split(",")] if os.environ.get("HS_TN") is not None and os.environ.get("HS_TN") != "" else (range(1, n_tn.value) if os.environ.get("HS_TN") is None else [])):
     g, t, tot = run(0, tn)
     print(f"tn={tn}: dw {t['gemm_bf16s_dw']:.1f} us   identical={torch.equal(g, ref)}", flush=True)

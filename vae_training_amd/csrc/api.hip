@@ -364,7 +364,9 @@ int vaek_ctx_create(const vaek_config* cfg, vaek_ctx** out) {
                             : l.n_out <= 32 ? (l.n_in + 1 + 127) / 128
                             : l.n_in + 1 <= 32 ? (l.n_out + 127) / 128
                             : ((l.n_in + 1 + 63) / 64) * ((l.n_out + 63) / 64);
-            const int s_target = std::min(256, std::max(4, (wide ? 768 : 1024) / tiles));
+            // at most 64 slabs: the fixed-order slab sum (bulk_finalize_kernel) is a chain of S / 8 memory round trips per output,
+            // and a 256-slab skinny layer (C3's 6 -> 512) held the whole finalize launch for ~60 us
+            const int s_target = std::min(64, std::max(4, (wide ? 768 : 1024) / tiles));
             l.rows_per_split = std::max(64, (int)align_up((size_t)(c->B + s_target - 1) / s_target, 64));
             l.S = (c->B + l.rows_per_split - 1) / l.rows_per_split;
             if (l.S > c->S) { c->S = l.S; c->rows_per_split = l.rows_per_split; }

@@ -295,7 +295,7 @@ int launch_finalize(const FinalizeArgs& a, hipStream_t st) {
     return VAEK_OK;
 }
 
-// Large models (C3: 1.06 M parameters, 14 slabs): the weights and biases [0, hi) are a plain streaming reduction --
+// Large models (C3: 1.06 M parameters, up to 256 slabs per layer): the weights and biases [0, hi) are a plain streaming reduction --
 // 16-byte loads, slab after slab in ascending order (the order finalize_kernel and sum_slabs_kernel use), Adam in the
 // same pass -- and finalize_kernel keeps only the tail it exists for (epsilon_p, epsilon, the loss sums), which
 // 64-output workgroups reading 256-byte runs of each slab did at 0.6 TB/s.
@@ -311,17 +311,15 @@ __global__ __launch_bounds__(256) void bulk_finalize_kernel(const FinalizeArgs a
     const bool vec = i0 + 3 < hi && slabs_of(i0 + 3) == S0 && a.slab_stride % 4 == 0 &&
                      (((uintptr_t)a.slabs | (uintptr_t)a.grads | (uintptr_t)a.params_rw | (uintptr_t)a.m | (uintptr_t)a.v) & 15) == 0;
     if (vec) {
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         // Adam state first: it does not depend on the sum, and issued here its latency hides under the slab loads
         float4 p = make_float4(0.f, 0.f, 0.f, 0.f), m = p, v = p;
         if (a.params_rw) {
             p = *reinterpret_cast<const float4*>(a.params_rw + i0); m = *reinterpret_cast<const float4*>(a.m + i0);
             v = *reinterpret_cast<const float4*>(a.v + i0);
         }
-        // 8 independent 16-byte loads in flight, summed in slab order.  Every load is UNCONDITIONAL (clamped slab index,
-        // the surplus selected away): a load under `s0 + u < S0 ? ... : 0` is waited for where it is issued (hipcc merges the
-        // loaded value into the zero inside the branch), which made this "8 in flight" loop a chain of single round trips --
-        // 199 us for 136 MB at C3 (0.8 TB/s).
+        // 8 independent 16-byte loads in flight, summed in slab order; every load unconditional (clamped slab index, the
+        // surplus selected away: a select on a loaded VALUE is a v_cndmask, a load under a condition is a wait)
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int s0 = 0; s0 < S0; s0 += 8) {
             float4 t[8];
 #pragma unroll
@@ -329,7 +327,7 @@ __global__ __launch_bounds__(256) void bulk_finalize_kernel(const FinalizeArgs a
                 t[u] = *reinterpret_cast<const float4*>(a.slabs + (long long)min(s0 + u, S0 - 1) * a.slab_stride + i0);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const bool in = s0 + u < S0;            // a select on a loaded VALUE is a v_cndmask, not a branch
+                const bool in = s0 + u < S0;
                 g.x += in ? t[u].x : 0.f; g.y += in ? t[u].y : 0.f; g.z += in ? t[u].z : 0.f; g.w += in ? t[u].w : 0.f;
             }
         }
@@ -342,10 +340,20 @@ __global__ __launch_bounds__(256) void bulk_finalize_kernel(const FinalizeArgs a
         }
         return;
     }
+    // A float4 that straddles a layer boundary (different slab counts), the end of the range or an unaligned buffer: element by
+    // element, but STILL with 8 loads in flight.  The plain `for (s) g += slabs[s * stride + i]` that used to stand here was one
+    // dependent round trip per slab, and ONE such thread at the seam of a 256-slab layer (C3's 6 -> 512 input layers) held the
+    // whole launch for 180 of its 199 us -- the streaming part itself runs in ~35 us.
     for (long long i = i0; i < std::min(hi, i0 + 4); ++i) {
         const int S = slabs_of(i);
         float g = 0.f;
-        for (int s = 0; s < S; ++s) g += a.slabs[(long long)s * a.slab_stride + i];
+        for (int s0 = 0; s0 < S; s0 += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = a.slabs[(long long)min(s0 + u, S - 1) * a.slab_stride + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g += s0 + u < S ? t[u] : 0.f;
+        }
         a.grads[i] = g;
         if (a.params_rw) {
             float p = a.params_rw[i], m = a.m[i], v = a.v[i];
@@ -454,7 +462,13 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* slabs, long
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float g = 0.f;
-    for (int s = 0; s < S; ++s) g += slabs[(long long)s * stride + i];
+    for (int s0 = 0; s0 < S; s0 += 8) {         // 8 unconditional loads in flight (clamped index), summed in slab order
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = slabs[(long long)min(s0 + u, S - 1) * stride + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) g += s0 + u < S ? t[u] : 0.f;
+    }
     out[i] = g;
 }
 

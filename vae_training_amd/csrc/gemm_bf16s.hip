@@ -45,6 +45,24 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
 
 enum { HS_FWD = 0, HS_DX = 1 };
 
+// Diagnostic build only (-DVAEK_HS_STAMPS, tools/hs_stamps.sh): per-wave s_memtime sums of the main loop's phases, written
+// to a buffer nothing else reads.  The shipped build contains no stamp.
+#ifdef VAEK_HS_STAMPS
+__device__ unsigned long long* g_hs_stamp_buf = nullptr;
+__device__ __forceinline__ unsigned long long hs_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define HS_STAMP(var) const unsigned long long var = hs_now()
+#define HS_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define HS_STAMP(var) do {} while (0)
+#define HS_ADD(acc, a, b) do {} while (0)
+#endif
+
 struct HsArgs {
     const __bf16* A; const __bf16* Bt; __bf16* C;   // A [M, K] (lda), Bt [N, K] (ldb), C [M, N] (ldc); K, N multiples of 64
     int M, N, K, lda, ldb, ldc;
@@ -78,6 +96,7 @@ __global__ __launch_bounds__(64 * WM * WN) void hs_nt_kernel(const HsArgs g) {
     static_assert(BM * CPR % NTH == 0 && BN * CPR % NTH == 0, "whole staging passes");
     static_assert(BK == 64 || BK == 32, "k-tile depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    HS_STAMP(k0);
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of the
     // n-fastest tile space so that the tiles sharing an A row panel hit one L2 (speed only)
     const unsigned tiles_n = (g.N + BN - 1) / BN, nb = gridDim.x;
@@ -124,13 +143,23 @@ __global__ __launch_bounds__(64 * WM * WN) void hs_nt_kernel(const HsArgs g) {
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
     const int nt = g.K / BK;
+#ifdef VAEK_HS_STAMPS
+    unsigned long long st_wait = 0, st_bar = 0, st_issue = 0, st_comp = 0;
+#endif
+    HS_STAMP(p0);
 #pragma unroll
     for (int q = 0; q < NS - 1; ++q) if (q < nt) stage(q, q);
+    HS_STAMP(p1);
     int slot = 0, fill = NS - 1;                          // ring positions of the tile being multiplied / being loaded
     for (int kt = 0; kt < nt; ++kt) {
+        HS_STAMP(s0);
         wait_tiles<P, NS - 2>(min(NS - 2, nt - 1 - kt));   // this wave's share of tile kt has landed ...
+        HS_STAMP(s1);
         __builtin_amdgcn_s_barrier();                      // ... and everyone's; everyone is done reading tile kt - 1
+        HS_STAMP(s2);
         if (kt + NS - 1 < nt) stage(kt + NS - 1, fill);    // into the slot tile kt - 1 was read from
+        HS_STAMP(s3);
+        HS_ADD(st_wait, s0, s1); HS_ADD(st_bar, s1, s2); HS_ADD(st_issue, s2, s3);
         const char* base = smem + slot * BUF;
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
@@ -147,7 +176,16 @@ __global__ __launch_bounds__(64 * WM * WN) void hs_nt_kernel(const HsArgs g) {
         }
         slot = slot + 1 == NS ? 0 : slot + 1;
         fill = fill + 1 == NS ? 0 : fill + 1;
+        HS_STAMP(s4);
+        HS_ADD(st_comp, s3, s4);
     }
+    HS_STAMP(e0);
+#ifdef VAEK_HS_STAMPS
+    if (g_hs_stamp_buf && lane == 0) {
+        unsigned long long* o = g_hs_stamp_buf + ((long long)blockIdx.x * (NTH / 64) + wv) * 8;
+        o[0] = p1 - p0; o[1] = st_wait; o[2] = st_bar; o[3] = st_issue; o[4] = st_comp; o[5] = e0 - p0; o[6] = k0; o[7] = e0;
+    }
+#endif
 
     // ---- epilogue: register q of tile (i, j) = C[m0 + wm.. + 32 i + r][nb + 32 j + (q & 3) + 8 (q >> 2) + 4 h]
     const int nbase = n0 + wn * (BN / WN);
@@ -203,6 +241,203 @@ __global__ __launch_bounds__(64 * WM * WN) void hs_nt_kernel(const HsArgs g) {
                 }
                 if (row_ok) *reinterpret_cast<uint4*>(g.C + rowoff + nj + 16 * u + 8 * h) = o;
             }
+        }
+    }
+#ifdef VAEK_HS_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HS_STAMP(x1);
+    if (g_hs_stamp_buf && lane == 0) g_hs_stamp_buf[((long long)gridDim.x * (NTH / 64) + (long long)blockIdx.x * (NTH / 64) + wv) * 8] = x1;
+#endif
+}
+
+// Persistent, staggered form of hs_nt_kernel for the big layers: one workgroup of 8 waves per CU walks its output tiles.
+//  * 256 x 256 tiles: a global_load_lds costs the issuing wave ~100-120 cycles per KB (tools/hs_stamps.sh), so a 128 x 128
+//    tile (0.5 KB per 32-cycle MFMA) is issue-bound; 256 x 256 loads 0.25 KB per MFMA.
+//  * stagger: every wave's k-tile is an issue phase (its share of the next tile's loads, ~500 cycles at BK = 32) and a
+//    multiply phase (16 MFMAs, 512 cycles); the two waves of a SIMD in lockstep leave the matrix pipe idle during the former
+//    and fight over it during the latter.  Waves 4-7 run multiply-then-issue, waves 0-3 issue-then-multiply.
+//  * the ring keeps filling across tile seams: the first stages of the NEXT tile are issued before the epilogue of this one,
+//    so the epilogue's stores run beside loads already in flight and no tile starts on an exposed HBM round trip.
+template <int EPI, int BM, int BN, int WM, int WN, int BK, int NS>
+__global__ __launch_bounds__(64 * WM * WN) void hs_nt_p_kernel(const HsArgs g) {
+    constexpr int NTH = 64 * WM * WN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int RB = 2 * BK, CPR = BK / 8;
+    constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, BUF = A_BYTES + B_BYTES;
+    constexpr int A_PASSES = BM * CPR / NTH, B_PASSES = BN * CPR / NTH, P = A_PASSES + B_PASSES;
+    static_assert(BM * CPR % NTH == 0 && BN * CPR % NTH == 0, "whole staging passes");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wv / WN, wn = wv % WN;
+    const bool late = wv >= WM * WN / 2;                 // wave-uniform: multiply first, issue afterwards
+    auto swz = [](int row) { return BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; };
+    // this workgroup's j-th tile; each XCD (workgroups b with equal b % 8) walks a contiguous run of the n-fastest tile space
+    const int G = gridDim.x, b = blockIdx.x;
+    const int my_tiles = b < ntiles ? (ntiles - b + G - 1) / G : 0;
+    auto tile_of = [&](int j, int& m0, int& n0) {
+        int L = b + j * G;
+        if (ntiles % 8 == 0 && G % 8 == 0) L = (b % 8) * (ntiles / 8) + (b / 8) + j * (G / 8);
+        m0 = (L / tiles_n) * BM; n0 = (L % tiles_n) * BN;
+    };
+    // staging positions of this thread (row, logical chunk) per pass: the swizzle lives in the source address
+    int a_row[A_PASSES], a_c[A_PASSES], b_row[B_PASSES], b_c[B_PASSES];
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) { const int p = i * NTH + t; a_row[i] = p / CPR; a_c[i] = ((p % CPR) ^ swz(p / CPR)) * 8; }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) { const int p = i * NTH + t; b_row[i] = p / CPR; b_c[i] = ((p % CPR) ^ swz(p / CPR)) * 8; }
+    const __bf16* a_src[A_PASSES]; const __bf16* b_src[B_PASSES];
+    auto set_sources = [&](int m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) a_src[i] = g.A + (long long)min(m0 + a_row[i], g.M - 1) * g.lda + a_c[i];
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i) b_src[i] = g.Bt + (long long)min(n0 + b_row[i], g.N - 1) * g.ldb + b_c[i];
+    };
+    auto stage = [&](int kt, int slot) {
+        char* base = smem + slot * BUF;
+#if defined(VAEK_HS_ABLATE) && (VAEK_HS_ABLATE & 4)      // diagnostic: no operand loads at all
+        (void)base; (void)kt;
+#else
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) glds16(a_src[i] + kt * BK, base + (i * NTH + wv * 64) * 16);
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i) glds16(b_src[i] + kt * BK, base + A_BYTES + (i * NTH + wv * 64) * 16);
+#endif
+    };
+    const int r = lane & 31, h = lane >> 5;
+    const int arow = wm * (BM / WM) + r, brow = wn * (BN / WN) + r;
+    const int ax = swz(arow), bx = swz(brow);
+    const int a_lo = arow * RB + ((h ^ ax) & 1) * 16, a_x6 = (ax & 6) * 16;
+    const int b_lo = brow * RB + ((h ^ bx) & 1) * 16 + A_BYTES, b_x6 = (bx & 6) * 16;
+    const float floor_v = g.relu ? 0.f : -__builtin_huge_valf();
+
+    // the bias of the tile being multiplied, loaded when the tile starts: a load issued in the epilogue would be YOUNGER than the
+    // next tile's stages already in flight, and vmcnt retires in order -- using it would drain the ring first
+    float4 bias4[TN][4];
+    auto load_bias = [&](int n0) {
+        if (EPI != HS_FWD) return;
+        const int nbase = min(n0 + wn * (BN / WN), g.N - BN / WN);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bias4[j][q] = *reinterpret_cast<const float4*>(g.bias + nbase + j * 32 + 8 * q + 4 * h);
+    };
+    f32x16 acc[TM][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    };
+    auto epilogue = [&](int m0, int n0) {
+        const int nbase = n0 + wn * (BN / WN);
+        if (nbase >= g.N) return;                      // wave-uniform: N is a multiple of 64 = the wave's column span
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * (BM / WM) + i * 32 + r;
+            const bool row_ok = m < g.M;
+            const long long rowoff = (long long)(row_ok ? m : g.M - 1) * g.ldc;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nj = nbase + j * 32;
+                uint4 mask[2];
+                if (EPI == HS_DX && g.aux) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) mask[u] = *reinterpret_cast<const uint4*>(g.aux + rowoff + nj + 16 * u + 8 * h);
+                }
+                unsigned d[4][2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) v[p] = acc[i][j][4 * q + p];
+                    if (EPI == HS_FWD) {
+                        const float4 bq = bias4[j][q];
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) v[p] = fmaxf(v[p] + (p == 0 ? bq.x : p == 1 ? bq.y : p == 2 ? bq.z : bq.w), floor_v);
+                    }
+                    d[q][0] = pack_bf16(v[0], v[1]); d[q][1] = pack_bf16(v[2], v[3]);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int qq = 2 * u;
+                    const auto sx = __builtin_amdgcn_permlane32_swap(d[qq][0], d[qq + 1][0], false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(d[qq][1], d[qq + 1][1], false, false);
+                    uint4 o = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                    if (EPI == HS_DX && g.aux) {
+                        auto keep = [](unsigned a) {
+                            const unsigned lo = (int)(short)(a & 0xffffu) > 0 ? 0xffffu : 0u;
+                            const unsigned hi = (int)a > 0xffff ? 0xffff0000u : 0u;
+                            return lo | hi;
+                        };
+                        o.x &= keep(mask[u].x); o.y &= keep(mask[u].y); o.z &= keep(mask[u].z); o.w &= keep(mask[u].w);
+                    }
+#if defined(VAEK_HS_ABLATE) && (VAEK_HS_ABLATE & 2)      // diagnostic: no output stores (values kept alive)
+                    asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
+#else
+                    if (row_ok) *reinterpret_cast<uint4*>(g.C + rowoff + nj + 16 * u + 8 * h) = o;
+#endif
+                }
+            }
+        }
+    };
+
+    // ---- one flat stream of k-tiles over all of this workgroup's output tiles: q = tile j * nt + kt --------------------
+    const int nt = g.K / BK, Q = my_tiles * nt;
+    if (Q == 0) return;
+    int lj = 0, lkt = 0;                                 // load cursor: tile index / k-tile of the NEXT stage to issue
+    int lm0, ln0; tile_of(0, lm0, ln0); set_sources(lm0, ln0);
+    int cm0 = lm0, cn0 = ln0, ckt = 0;                   // compute cursor
+    auto issue_next = [&](int slot) {                    // issue stage number `issued`, advance the load cursor
+        stage(lkt, slot);
+        if (++lkt == nt) { lkt = 0; ++lj; if (lj < my_tiles) { tile_of(lj, lm0, ln0); set_sources(lm0, ln0); } }
+    };
+    int issued = 0;
+#pragma unroll
+    for (int qq = 0; qq < NS - 1; ++qq) if (issued < Q) { issue_next(qq); ++issued; }
+    int slot = 0, fill = NS - 1, cj = 0;
+    zero_acc();
+    load_bias(cn0);
+    for (int q = 0; q < Q; ++q) {
+        // loads of the stores of an earlier epilogue count in vmcnt too, but they are OLDER than every tile in flight, so
+        // "at most P * newer outstanding" still implies tile q has landed
+        wait_tiles<P, NS - 2>(min(NS - 2, Q - 1 - q));
+        __builtin_amdgcn_s_barrier();
+        const bool more = issued < Q;
+        if (!late && more) issue_next(fill);
+        const char* base = smem + slot * BUF;
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(base + a_lo + i * 32 * RB + ((32 * s) ^ a_x6));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(base + b_lo + j * 32 * RB + ((32 * s) ^ b_x6));
+#if defined(VAEK_HS_ABLATE) && (VAEK_HS_ABLATE & 1)      // diagnostic (tools/hs_ablate.sh): no MFMAs, operands kept alive
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb[j]));
+#else
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+#endif
+        }
+        if (late && more) issue_next(fill);
+        if (more) ++issued;
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        fill = fill + 1 == NS ? 0 : fill + 1;
+        if (++ckt == nt) {                               // this output tile is complete (the next one's loads are already in flight)
+            epilogue(cm0, cn0);
+            zero_acc();
+            ckt = 0; ++cj;
+            if (cj < my_tiles) { tile_of(cj, cm0, cn0); load_bias(cn0); }
         }
     }
 }
@@ -360,10 +595,13 @@ __global__ __launch_bounds__(256) void cvt_w_kernel(const float* __restrict__ pa
 // ---- launchers ----------------------------------------------------------------------------------------------------------
 // Tile / ring variants (tools/hs_tune.py times them on the box through vaek_debug_hs_gemm; g_hs_variant_* pick the default).
 typedef void (*HsNtKernel)(const HsArgs);
-struct HsNtVariant { HsNtKernel fwd, dx; int bm, bn, nth; size_t lds; const char* name; };
+struct HsNtVariant { HsNtKernel fwd, dx; int bm, bn, nth; size_t lds; const char* name; int persistent; };
+#define HS_NTP(BM, BN, WM, WN, BK, NS) \
+    {hs_nt_p_kernel<HS_FWD, BM, BN, WM, WN, BK, NS>, hs_nt_p_kernel<HS_DX, BM, BN, WM, WN, BK, NS>, BM, BN, 64 * WM * WN, \
+     (size_t)NS * (BM + BN) * 2 * BK, #BM "x" #BN "x" #BK " ring" #NS " persistent staggered", 1}
 #define HS_NT(BM, BN, WM, WN, BK, NS) \
     {hs_nt_kernel<HS_FWD, BM, BN, WM, WN, BK, NS>, hs_nt_kernel<HS_DX, BM, BN, WM, WN, BK, NS>, BM, BN, 64 * WM * WN, \
-     (size_t)NS * (BM + BN) * 2 * BK, #BM "x" #BN "x" #BK " ring" #NS}
+     (size_t)NS * (BM + BN) * 2 * BK, #BM "x" #BN "x" #BK " ring" #NS, 0}
 static const HsNtVariant kNt[] = {
     HS_NT(128, 128, 2, 2, 64, 2),      // 0: one tile of prefetch, 64 KB, two workgroups per CU (the first version)
     HS_NT(128, 128, 2, 2, 32, 5),      // 1: 16 KB stages, four in flight, 80 KB, two workgroups per CU
@@ -372,6 +610,16 @@ static const HsNtVariant kNt[] = {
     HS_NT(256, 128, 4, 2, 32, 6),      // 4: 24 KB stages, five in flight, 144 KB, 8 waves
     HS_NT(128, 128, 2, 2, 32, 4),      // 5: 16 KB stages, three in flight, 64 KB, two workgroups per CU
     HS_NT(128, 128, 2, 2, 32, 3),      // 6: 48 KB: three workgroups per CU
+    // a global_load_lds costs the issuing wave ~100 cycles per KB (in-kernel stamps, tools/hs_stamps.sh): a 128 x 128 tile
+    // loads 0.5 KB per 32-cycle MFMA -- issue-bound; 256 x 256 loads 0.25 KB per MFMA
+    HS_NT(256, 256, 2, 4, 64, 2),      // 7: 128 KB, one workgroup of 8 waves per CU, wave tile 128 x 64
+    HS_NT(256, 256, 4, 2, 64, 2),      // 8: wave tile 64 x 128
+    HS_NT(256, 256, 2, 4, 32, 4),      // 9: 32 KB stages, three in flight
+    HS_NT(256, 128, 4, 2, 64, 2),      // 10: 96 KB
+    HS_NTP(256, 256, 2, 4, 32, 4),     // 11: persistent + staggered, 32 KB stages, three in flight, 128 KB
+    HS_NTP(256, 256, 2, 4, 32, 5),     // 12: four in flight, 160 KB
+    HS_NTP(256, 256, 4, 2, 32, 4),     // 13: wave tile 64 x 128
+    HS_NTP(256, 128, 4, 2, 32, 4),     // 14: 96 KB
 };
 constexpr int kNtCount = sizeof(kNt) / sizeof(kNt[0]);
 typedef void (*HsTnKernel)(const HsDwArgs);
@@ -399,7 +647,8 @@ static int hs_launch_nt(const HsArgs& g, const char* label, hipStream_t st) {
         VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
         attr_set[EPI][vi] = true;
     }
-    const unsigned grid = (unsigned)(((g.M + v.bm - 1) / v.bm) * ((g.N + v.bn - 1) / v.bn));
+    unsigned grid = (unsigned)(((g.M + v.bm - 1) / v.bm) * ((g.N + v.bn - 1) / v.bn));
+    if (v.persistent) grid = std::min(grid, 256u);         // one resident workgroup per CU walks the tiles
     ProfScope ps(label, st);
     launch_k(ps, fn, dim3(grid), dim3(v.nth), v.lds, st, g);
     VAEK_HIP_CHECK(hipGetLastError());
@@ -472,3 +721,9 @@ extern "C" int vaek_debug_hs_variant(int nt, int tn, int* n_nt, int* n_tn) {
     if (n_tn) *n_tn = vaek::kTnCount;
     return VAEK_OK;
 }
+
+#ifdef VAEK_HS_STAMPS
+extern "C" int vaek_debug_hs_stamps(unsigned long long* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(vaek::g_hs_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -2;
+}
+#endif
