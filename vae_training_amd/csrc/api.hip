@@ -97,7 +97,20 @@ static int convert_weights(vaek_ctx* c, const float* params, void* ws, hipStream
             K[n] = net->layers[i].n_in; N[n] = net->layers[i].n_out; woff[n] = net->layers[i].w_off; ooff[n] = net->wb_off[i]; ++n;
         }
     }
-    return launch_cvt_weights(params, reinterpret_cast<__bf16*>(static_cast<char*>(ws) + c->ws_wb16), K, N, woff, ooff, n, st);
+    int rc = launch_cvt_weights(params, reinterpret_cast<__bf16*>(static_cast<char*>(ws) + c->ws_wb16), K, N, woff, ooff, n, st);
+    if (rc) return rc;
+    // 32-row padded bf16 copies for the skinny first / last layers (gemm_skinny16.hip)
+    int H[16], d[16], tr[16], m = 0; int64_t sw[16], so[16];
+    for (const Net* net : {&c->enc, &c->dec, &c->sig}) {
+        if (!net->b16) continue;
+        const Layer& f = net->layers.front(); const Layer& l = net->layers.back();
+        if (f.sk && m < 16) { H[m] = f.n_out; d[m] = f.n_in; tr[m] = 0; sw[m] = f.w_off; so[m] = f.sk_off; ++m; }
+        if (l.sk && m < 16) { H[m] = l.n_in; d[m] = l.n_out; tr[m] = 1; sw[m] = l.w_off; so[m] = l.sk_off; ++m; }
+    }
+    return launch_sk_prep(params, reinterpret_cast<__bf16*>(static_cast<char*>(ws) + c->ws_sk16), H, d, tr, sw, so, m, st);
+}
+static inline __bf16* sk16(const vaek_ctx* c, void* ws, const Layer& l) {
+    return reinterpret_cast<__bf16*>(static_cast<char*>(ws) + c->ws_sk16) + l.sk_off;
 }
 
 // ---- forward through one Dense/relu stack; `reparam` fuses networks.py:73-74 into the last layer
@@ -117,8 +130,14 @@ static int net_forward(vaek_ctx* c, const Net& net, const float* params, const f
         if (net.b16) {
             const bool last = i + 1 == net.layers.size();
             const __bf16* h16p = reinterpret_cast<const __bf16*>(h);
-            if (i == 0) rc = launch_dense_fwd_out16(h, w, b, reinterpret_cast<__bf16*>(y), rows, l.n_in, l.n_out, l.relu, st);
+            if (i == 0 && l.sk) rc = launch_sk_first_fwd(h, w, b, reinterpret_cast<__bf16*>(y), rows, l.n_in, l.n_out, l.relu, st);
+            else if (i == 0) rc = launch_dense_fwd_out16(h, w, b, reinterpret_cast<__bf16*>(y), rows, l.n_in, l.n_out, l.relu, st);
             else if (!last) rc = launch_hs_fwd(h16p, wb16(c, ws, net, i, true), b, reinterpret_cast<__bf16*>(y), rows, l.n_in, l.n_out, l.relu, st);
+            else if (l.sk && ef) rc = launch_sk_last_fwd_elbo(h16p, sk16(c, ws, l), b, y, ef->x, ef->z2, ef->eps_param, ef->eps_cli, ef->inv_bt,
+                                                              ef->part, rows, l.n_in, l.n_out, &ef->bm, &ef->nbx, st);
+            else if (l.sk && reparam) rc = launch_sk_last_fwd_reparam(h16p, sk16(c, ws, l), b, y, at<float>(ws, c->ws_samples), z1,
+                                                                      params + c->off_epsp, rows, l.n_in, l.n_out, st);
+            else if (l.sk) rc = launch_sk_last_fwd(h16p, sk16(c, ws, l), b, y, rows, l.n_in, l.n_out, st);
             else if (ef) rc = launch_dense_fwd_elbo_in16(h16p, w, b, y, ef->x, ef->z2, ef->eps_param, ef->eps_cli, ef->inv_bt, ef->part, rows,
                                                          l.n_in, l.n_out, &ef->bm, &ef->nbx, st);
             else if (reparam) rc = launch_dense_fwd_reparam_in16(h16p, w, b, y, at<float>(ws, c->ws_samples), z1, params + c->off_epsp, rows,
@@ -166,7 +185,12 @@ static int net_backward(vaek_ctx* c, const Net& net, const float* params, const 
             const bool last = i + 1 == (int)net.layers.size();
             const __bf16* h_in16 = reinterpret_cast<const __bf16*>(h_in);
             const __bf16* d16 = reinterpret_cast<const __bf16*>(d);
-            if (last) rc = launch_dense_bwd_dw_x16(h_in16, d, slabs + l.w_off, slab_stride(c), l.S, l.rows_per_split, c->B, l.n_in, l.n_out, st);
+            float* skpart = at<float>(ws, c->ws_skpart);
+            if (last && l.sk)        // dW|db AND dX (into the ping-pong buffer the dX branch below would have used) from one pass over h
+                rc = launch_sk_last_bwd(h_in16, d, w, reinterpret_cast<__bf16*>(gb[tog]), skpart, slabs + l.w_off, slab_stride(c), l.S, c->B,
+                                        l.n_in, l.n_out, st);
+            else if (i == 0 && l.sk) rc = launch_sk_first_bwd(h_in, d16, skpart, slabs + l.w_off, slab_stride(c), l.S, c->B, l.n_out, l.n_in, st);
+            else if (last) rc = launch_dense_bwd_dw_x16(h_in16, d, slabs + l.w_off, slab_stride(c), l.S, l.rows_per_split, c->B, l.n_in, l.n_out, st);
             else if (i == 0) rc = launch_dense_bwd_dw_dy16(h_in, d16, slabs + l.w_off, slab_stride(c), l.S, l.rows_per_split, c->B, l.n_in, l.n_out, st);
             else rc = launch_hs_dw(h_in16, d16, slabs + l.w_off, slab_stride(c), l.S, l.rows_per_split, c->B, l.n_in, l.n_out, st);
         } else {
@@ -185,7 +209,8 @@ static int net_backward(vaek_ctx* c, const Net& net, const float* params, const 
             if (net.b16) {
                 const __bf16* h_in16 = reinterpret_cast<const __bf16*>(h_in);
                 if (i + 1 == (int)net.layers.size())
-                    rc = launch_dense_bwd_dx_out16(d, w, h_in16, reinterpret_cast<__bf16*>(dx), c->B, l.n_in, l.n_out, false, st);
+                    rc = l.sk ? VAEK_OK      // already written by launch_sk_last_bwd above
+                              : launch_dense_bwd_dx_out16(d, w, h_in16, reinterpret_cast<__bf16*>(dx), c->B, l.n_in, l.n_out, false, st);
                 else
                     rc = launch_hs_dx(reinterpret_cast<const __bf16*>(d), wb16(c, ws, net, i, false), h_in16, reinterpret_cast<__bf16*>(dx),
                                       c->B, l.n_in, l.n_out, st);
@@ -195,7 +220,9 @@ static int net_backward(vaek_ctx* c, const Net& net, const float* params, const 
             if (rc) return rc;
             d = dx;
         } else if (dx_first) {
-            if (net.b16)
+            if (net.b16 && l.sk)
+                rc = launch_sk_first_dx(reinterpret_cast<const __bf16*>(d), sk16(c, ws, l), dx_first, c->B, l.n_out, l.n_in, accumulate_first, st);
+            else if (net.b16)
                 rc = launch_dense_bwd_dx_in16(reinterpret_cast<const __bf16*>(d), w, dx_first, c->B, l.n_in, l.n_out, accumulate_first, st);
             else
                 rc = (h16 ? launch_dense_bwd_dx_bf16 : launch_dense_bwd_dx)(d, w, nullptr, dx_first, c->B, l.n_in, l.n_out, false,
@@ -389,6 +416,21 @@ int vaek_ctx_create(const vaek_config* cfg, vaek_ctx** out) {
             wb_elems += 2 * (int64_t)l.n_in * l.n_out;
         }
     }
+    // ... and its skinny ends (gemm_skinny16.hip): S slabs, each the fixed-order sum of 64 workgroups' partial images
+    int64_t sk_elems = 0; size_t sk_part = 0;
+    for (Net* net : {&c->enc, &c->dec, &c->sig}) {
+        if (!net->b16) continue;
+        for (Layer* l : {&net->layers.front(), &net->layers.back()}) {
+            const bool first = l == &net->layers.front();
+            const int d = first ? l->n_in : l->n_out, H = first ? l->n_out : l->n_in;
+            if (!sk_supported(d, H)) continue;
+            l->sk = true;
+            l->S = std::min(8, std::max(1, c->B / 4096));
+            l->rows_per_split = (c->B + l->S - 1) / l->S;
+            l->sk_off = sk_elems; sk_elems += 32ll * H;
+            sk_part = std::max(sk_part, sk_partial_bytes(d, H, l->S));
+        }
+    }
     c->S = 1; c->rows_per_split = c->B;
     for (const Net* net : {&c->enc, &c->dec, &c->sig})
         for (const auto& l : net->layers) if (l.S > c->S) { c->S = l.S; c->rows_per_split = l.rows_per_split; }
@@ -414,6 +456,8 @@ int vaek_ctx_create(const vaek_config* cfg, vaek_ctx** out) {
     c->fused = !cfg->force_generic && fused_supported(c);
     c->ws_fused = off; off = align_up(off + fused_workspace_bytes(c), 256);
     c->ws_wb16 = off; off = align_up(off + (size_t)wb_elems * sizeof(__bf16), 256);
+    c->ws_sk16 = off; off = align_up(off + (size_t)sk_elems * sizeof(__bf16), 256);
+    c->ws_skpart = off; off = align_up(off + sk_part, 256);
     c->ws_total = off;
     *out = c;
     return VAEK_OK;

@@ -1,0 +1,442 @@
+// The skinny ends of a bf16-storage stack (api.hip, Net::b16): the first layer d -> H and the last layer H -> d of an MLP
+// whose hidden width H is wide and whose data / latent dimension d is a handful of features (every shipped experiment:
+// d = 6, 7, 12, 20; networks.py:26-44 via vae.py:53-54).  Each of these layers touches ONE big tensor, the [B, H] bf16
+// activation or gradient (67 MB at C3), so its roofline is that tensor's HBM stream; on the general f32 matrix-core kernel
+// (gemm_f32.hip, d padded to a 32-wide MFMA tile, f32 MFMA = 1/16 of the bf16 rate) they ran 2-3x over it and together
+// made up a third of the C3 bf16 step.  Four kernels, all reading / writing the big tensor in 16-byte pieces, fully coalesced:
+//
+//   sk_first_fwd    y[B,H] = relu(x[B,d] W[d,H] + b) as bf16.  VALU: a lane owns 8 output columns, the d x 8 weights live
+//                   in its registers, x rows are broadcast loads.                                   (one 67 MB write)
+//   sk_rows_mfma    C[B,d] = A[B,H] . Wp^T on v_mfma_f32_32x32x16_bf16 with A fragments straight from global memory (each
+//                   element is used by exactly one MFMA: staging it through LDS would buy nothing) and Wp = the weights
+//                   padded to 32 rows, bf16, k-contiguous.  Epilogues: bias (+ accumulate), reparameterisation
+//                   (networks.py:73-74), the ELBO's elementwise pass (networks.py:81-83, 94-98).  Serves the last layer's
+//                   forward AND the first layer's dX (A = dY).                                       (one 67 MB read)
+//   sk_last_bwd     last layer backward, dX and dW|db FUSED: dh[B,H] = (dy[B,d] W^T) * (h > 0) as bf16 and G[(H+1),d] =
+//                   [h | 1]^T dy from ONE pass over h.                                    (one 67 MB read, one 67 MB write)
+//   sk_first_bwd    first layer dW|db: G[(d+1),H] = [x | 1]^T dY.                                    (one 67 MB read)
+//
+// Batch reductions (G) are per-workgroup register sums -> one partial image per workgroup -> sk_partials_reduce sums fixed
+// groups of 64 partials in fixed order into the layer's S slabs (flat-gradient layout, as every other dW kernel writes them):
+// no atomics, bitwise repeatable.
+#include "vaek_internal.h"
+
+namespace vaek {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+
+__device__ __forceinline__ unsigned sk_pack(float lo, float hi) {
+    const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void sk_unpack8(const uint4 u, float (&f)[8]) {      // bf16 -> f32 is a 16-bit shift
+    f[0] = __builtin_bit_cast(float, u.x << 16); f[1] = __builtin_bit_cast(float, u.x & 0xffff0000u);
+    f[2] = __builtin_bit_cast(float, u.y << 16); f[3] = __builtin_bit_cast(float, u.y & 0xffff0000u);
+    f[4] = __builtin_bit_cast(float, u.z << 16); f[5] = __builtin_bit_cast(float, u.z & 0xffff0000u);
+    f[6] = __builtin_bit_cast(float, u.w << 16); f[7] = __builtin_bit_cast(float, u.w & 0xffff0000u);
+}
+
+// ---- first layer forward ------------------------------------------------------------------------------------------------
+struct SkFwdArgs { const float* x; const float* w; const float* b; __bf16* y; int rows, d, H, relu; };
+
+template <int DMAX>
+__global__ __launch_bounds__(256) void sk_first_fwd_kernel(const SkFwdArgs a) {
+    const int cprw = a.H >> 3, rpp = 256 / cprw, t = threadIdx.x;
+    if (t >= rpp * cprw) return;
+    const int chunk = t % cprw, rsub = t / cprw;
+    float w[DMAX][8], b8[8];
+#pragma unroll
+    for (int i = 0; i < DMAX; ++i) {                    // unconditional loads (clamped row), zeroed by a select afterwards
+        const float4 lo = *reinterpret_cast<const float4*>(a.w + (long long)min(i, a.d - 1) * a.H + 8 * chunk);
+        const float4 hi = *reinterpret_cast<const float4*>(a.w + (long long)min(i, a.d - 1) * a.H + 8 * chunk + 4);
+        const bool in = i < a.d;
+        w[i][0] = in ? lo.x : 0.f; w[i][1] = in ? lo.y : 0.f; w[i][2] = in ? lo.z : 0.f; w[i][3] = in ? lo.w : 0.f;
+        w[i][4] = in ? hi.x : 0.f; w[i][5] = in ? hi.y : 0.f; w[i][6] = in ? hi.z : 0.f; w[i][7] = in ? hi.w : 0.f;
+    }
+    {
+        const float4 lo = *reinterpret_cast<const float4*>(a.b + 8 * chunk), hi = *reinterpret_cast<const float4*>(a.b + 8 * chunk + 4);
+        b8[0] = lo.x; b8[1] = lo.y; b8[2] = lo.z; b8[3] = lo.w; b8[4] = hi.x; b8[5] = hi.y; b8[6] = hi.z; b8[7] = hi.w;
+    }
+    const float floor_v = a.relu ? 0.f : -__builtin_huge_valf();
+    for (long long row = (long long)blockIdx.x * rpp + rsub; row < a.rows; row += (long long)gridDim.x * rpp) {
+        float xi[DMAX];
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i) xi[i] = a.x[row * a.d + min(i, a.d - 1)];       // rows i >= d meet zero weights
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = b8[j];
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = fmaf(xi[i], w[i][j], o[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], floor_v);
+        *reinterpret_cast<uint4*>(a.y + row * a.H + 8 * chunk) =
+            make_uint4(sk_pack(o[0], o[1]), sk_pack(o[2], o[3]), sk_pack(o[4], o[5]), sk_pack(o[6], o[7]));
+    }
+}
+
+// ---- rows x small matrix on the bf16 matrix cores ---------------------------------------------------------------------------
+enum { SK_PLAIN = 0, SK_REPARAM = 1, SK_ELBO = 2 };
+struct SkRowsArgs {
+    const __bf16* A; const __bf16* Bt; int M, K, d, lda;      // A [M, K]; Bt [32, K] (rows >= d are zero)
+    float* C; int ldc; const float* bias; int accumulate;
+    float* C2; const float* z1; const float* lv;              // REPARAM: C = mu, C2 = samples
+    const float* x; const float* z2; const float* eps_param; float eps_cli, inv_bt; float* part;   // ELBO: C = dL/dx_hat
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256) void sk_rows_mfma_kernel(const SkRowsArgs a) {
+    __shared__ float red[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const long long m = (long long)blockIdx.x * 128 + wave * 32 + r;
+    const bool row_ok = m < a.M;
+    const __bf16* ap = a.A + (row_ok ? m : (long long)a.M - 1) * a.lda + 8 * h;
+    const __bf16* bp = a.Bt + (long long)r * a.K + 8 * h;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    for (int k0 = 0; k0 < a.K; k0 += 64) {           // K is a multiple of 64: four 16-deep steps, eight loads in flight
+        bf16x8 av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            av[u] = *reinterpret_cast<const bf16x8*>(ap + k0 + 16 * u);
+            bv[u] = *reinterpret_cast<const bf16x8*>(bp + k0 + 16 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)                  // swapped operands: D[n][m] -- lane & 31 = row m, registers = columns n
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[u], av[u], acc, 0, 0, 0);
+    }
+    float e_mse = 0.f, e_deps = 0.f, e_inv_var = 0.f, e_sigma = 0.f, e_dscale = 0.f;
+    if (EPI == SK_ELBO) {
+        const float eps = a.eps_param ? a.eps_param[0] * a.eps_cli : a.eps_cli;
+        e_inv_var = expf(-eps); e_sigma = expf(0.5f * eps); e_dscale = e_inv_var * a.inv_bt;
+    }
+    // register q = column (q & 3) + 8 (q >> 2) + 4 h of row m
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int n = (q & 3) + 8 * (q >> 2) + 4 * h;
+        if (n >= a.d || !row_ok) continue;
+        const long long o = m * a.ldc + n;
+        float v = acc[q] + (a.bias ? a.bias[n] : 0.f);
+        if (EPI == SK_PLAIN) {
+            if (a.accumulate) v += a.C[o];
+            a.C[o] = v;
+        } else if (EPI == SK_REPARAM) {
+            a.C[o] = v;
+            a.C2[o] = v + expf(0.5f * a.lv[n]) * a.z1[o];
+        } else {
+            const float z = a.z2[o];
+            const float rr = v + e_sigma * z - a.x[o];               // x_hat - x, x_hat = y + z2 e^{eps/2}
+            const float qq = rr * rr * e_inv_var;
+            e_mse += 0.5f * qq;
+            e_deps += -0.5f * qq + 0.5f * e_sigma * z * rr * e_inv_var;
+            a.C[o] = rr * e_dscale;
+        }
+    }
+    if (EPI == SK_ELBO) {      // this workgroup's two sums, fixed order: lanes by xor-shuffle, then the four waves in order
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) { e_mse += __shfl_xor(e_mse, s, 64); e_deps += __shfl_xor(e_deps, s, 64); }
+        if (lane == 0) { red[2 * wave] = e_mse; red[2 * wave + 1] = e_deps; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            a.part[2 * (long long)blockIdx.x] = ((red[0] + red[2]) + red[4]) + red[6];
+            a.part[2 * (long long)blockIdx.x + 1] = ((red[1] + red[3]) + red[5]) + red[7];
+        }
+    }
+}
+
+// ---- last layer backward: dX and dW|db from one pass over h ----------------------------------------------------------------
+struct SkBwdArgs {
+    const __bf16* big;      // last: h [rows, H] (the layer's bf16 input); first: dY [rows, H]
+    const float* small;     // last: dy [rows, d]; first: x [rows, d]
+    const float* w;         // last: W [H, d]
+    __bf16* dh;             // last: [rows, H]
+    float* partial;         // [gridDim.x][(H + 1) d] resp. [(d + 1) H]
+    int rows, d, H, rows_per_wg;
+};
+
+template <int DMAX>
+__global__ __launch_bounds__(256) void sk_last_bwd_kernel(const SkBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sk_lds[];
+    const int cprw = a.H >> 3, rpp = 256 / cprw, t = threadIdx.x;
+    const bool active = t < rpp * cprw;
+    const int chunk = active ? t % cprw : 0, rsub = active ? t / cprw : 0;
+    float w[8][DMAX], g[8][DMAX], gb[DMAX];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int n = 0; n < DMAX; ++n) {
+            const float v = a.w[(long long)(8 * chunk + j) * a.d + min(n, a.d - 1)];
+            w[j][n] = n < a.d ? v : 0.f;
+            g[j][n] = 0.f;
+        }
+#pragma unroll
+    for (int n = 0; n < DMAX; ++n) gb[n] = 0.f;
+    const long long r0 = (long long)blockIdx.x * a.rows_per_wg, r1 = min((long long)a.rows, r0 + a.rows_per_wg);
+    if (active)
+        for (long long row = r0 + rsub; row < r1; row += rpp) {
+            const uint4 hv = *reinterpret_cast<const uint4*>(a.big + row * a.H + 8 * chunk);
+            float dyv[DMAX];
+#pragma unroll
+            for (int n = 0; n < DMAX; ++n) { const float v = a.small[row * a.d + min(n, a.d - 1)]; dyv[n] = n < a.d ? v : 0.f; }
+            float hf[8], o[8];
+            sk_unpack8(hv, hf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int n = 0; n < DMAX; ++n) { s = fmaf(dyv[n], w[j][n], s); g[j][n] = fmaf(hf[j], dyv[n], g[j][n]); }
+                o[j] = hf[j] > 0.f ? s : 0.f;                                  // relu'
+            }
+#pragma unroll
+            for (int n = 0; n < DMAX; ++n) gb[n] += dyv[n];
+            *reinterpret_cast<uint4*>(a.dh + row * a.H + 8 * chunk) =
+                make_uint4(sk_pack(o[0], o[1]), sk_pack(o[2], o[3]), sk_pack(o[4], o[5]), sk_pack(o[6], o[7]));
+        }
+    // the rpp row phases of a column chunk: phases 1.. park their sums in LDS, phase 0 adds them in order
+    const int per = 8 * a.d + a.d;                          // floats a thread contributes: its 8 x d block, then gb
+    if (active && rsub > 0) {
+        float* p = sk_lds + ((long long)(rsub - 1) * cprw + chunk) * per;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int n = 0; n < DMAX; ++n) if (n < a.d) p[j * a.d + n] = g[j][n];
+#pragma unroll
+        for (int n = 0; n < DMAX; ++n) if (n < a.d) p[8 * a.d + n] = gb[n];
+    }
+    __syncthreads();
+    if (active && rsub == 0) {
+        for (int s = 1; s < rpp; ++s) {
+            const float* p = sk_lds + ((long long)(s - 1) * cprw + chunk) * per;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int n = 0; n < DMAX; ++n) if (n < a.d) g[j][n] += p[j * a.d + n];
+#pragma unroll
+            for (int n = 0; n < DMAX; ++n) if (n < a.d) gb[n] += p[8 * a.d + n];
+        }
+        float* out = a.partial + (long long)blockIdx.x * ((long long)(a.H + 1) * a.d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int n = 0; n < DMAX; ++n) if (n < a.d) out[(long long)(8 * chunk + j) * a.d + n] = g[j][n];
+        if (chunk == 0) {
+#pragma unroll
+            for (int n = 0; n < DMAX; ++n) if (n < a.d) out[(long long)a.H * a.d + n] = gb[n];
+        }
+    }
+}
+
+// ---- first layer dW|db ---------------------------------------------------------------------------------------------------
+template <int DMAX>
+__global__ __launch_bounds__(256) void sk_first_bwd_kernel(const SkBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sk_lds[];
+    const int cprw = a.H >> 3, rpp = 256 / cprw, t = threadIdx.x;
+    const bool active = t < rpp * cprw;
+    const int chunk = active ? t % cprw : 0, rsub = active ? t / cprw : 0;
+    float g[DMAX + 1][8];
+#pragma unroll
+    for (int i = 0; i <= DMAX; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[i][j] = 0.f;
+    const long long r0 = (long long)blockIdx.x * a.rows_per_wg, r1 = min((long long)a.rows, r0 + a.rows_per_wg);
+    if (active)
+        for (long long row = r0 + rsub; row < r1; row += rpp) {
+            const uint4 dv = *reinterpret_cast<const uint4*>(a.big + row * a.H + 8 * chunk);
+            float xi[DMAX], df[8];
+#pragma unroll
+            for (int i = 0; i < DMAX; ++i) { const float v = a.small[row * a.d + min(i, a.d - 1)]; xi[i] = i < a.d ? v : 0.f; }
+            sk_unpack8(dv, df);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int i = 0; i < DMAX; ++i) g[i][j] = fmaf(xi[i], df[j], g[i][j]);
+                g[DMAX][j] += df[j];                                          // the ones row of [x | 1]^T dY
+            }
+        }
+    const int per = (a.d + 1) * 8;
+    if (active && rsub > 0) {
+        float* p = sk_lds + ((long long)(rsub - 1) * cprw + chunk) * per;
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (i < a.d) p[i * 8 + j] = g[i][j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[a.d * 8 + j] = g[DMAX][j];
+    }
+    __syncthreads();
+    if (active && rsub == 0) {
+        for (int s = 1; s < rpp; ++s) {
+            const float* p = sk_lds + ((long long)(s - 1) * cprw + chunk) * per;
+#pragma unroll
+            for (int i = 0; i < DMAX; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (i < a.d) g[i][j] += p[i * 8 + j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[DMAX][j] += p[a.d * 8 + j];
+        }
+        float* out = a.partial + (long long)blockIdx.x * ((long long)(a.d + 1) * a.H);
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i)
+            if (i < a.d) {
+                *reinterpret_cast<float4*>(out + (long long)i * a.H + 8 * chunk) = make_float4(g[i][0], g[i][1], g[i][2], g[i][3]);
+                *reinterpret_cast<float4*>(out + (long long)i * a.H + 8 * chunk + 4) = make_float4(g[i][4], g[i][5], g[i][6], g[i][7]);
+            }
+        *reinterpret_cast<float4*>(out + (long long)a.d * a.H + 8 * chunk) = make_float4(g[DMAX][0], g[DMAX][1], g[DMAX][2], g[DMAX][3]);
+        *reinterpret_cast<float4*>(out + (long long)a.d * a.H + 8 * chunk + 4) = make_float4(g[DMAX][4], g[DMAX][5], g[DMAX][6], g[DMAX][7]);
+    }
+}
+
+// slab[s][i] = sum of partial[s * G + w][i], w = 0 .. G - 1 in order, 8 loads in flight
+__global__ __launch_bounds__(256) void sk_partials_reduce_kernel(const float* partial, long long n, int G, float* slab0, long long slab_stride) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* p = partial + (long long)blockIdx.y * G * n + i;
+    float s = 0.f;
+    for (int w0 = 0; w0 < G; w0 += 8) {
+        float tv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tv[u] = p[(long long)min(w0 + u, G - 1) * n];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += w0 + u < G ? tv[u] : 0.f;
+    }
+    slab0[(long long)blockIdx.y * slab_stride + i] = s;
+}
+
+// bf16, 32-row padded, k-contiguous copies of the skinny kernels for sk_rows_mfma: transposed = 1: src W [H, d] (last layer
+// forward), out[n][k] = W[k][n]; transposed = 0: src W [d, H] (first layer dX), out[n][k] = W[n][k]
+struct SkPrepArgs { int n; int H[16], d[16], transposed[16]; long long w_off[16], out_off[16]; };
+__global__ __launch_bounds__(256) void sk_prep_kernel(const float* __restrict__ params, __bf16* __restrict__ out, const SkPrepArgs a) {
+    const int l = blockIdx.y, H = a.H[l], d = a.d[l];
+    const float* w = params + a.w_off[l];
+    __bf16* o = out + a.out_off[l];
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < 32 * H; e += gridDim.x * 256) {
+        const int n = e / H, k = e % H;
+        const float v = n < d ? (a.transposed[l] ? w[(long long)k * d + n] : w[(long long)n * H + k]) : 0.f;
+        o[e] = (__bf16)v;
+    }
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------------------------------
+bool sk_supported(int d, int H) { return d >= 1 && d <= 16 && H % 64 == 0 && H >= 64 && H <= 2048; }
+
+int launch_sk_first_fwd(const float* x, const float* w, const float* b, __bf16* y, int rows, int d, int H, bool relu, hipStream_t st) {
+    SkFwdArgs a{x, w, b, y, rows, d, H, relu ? 1 : 0};
+    const int rpp = 256 / (H / 8);
+    const unsigned grid = (unsigned)std::min<long long>(((long long)rows + rpp - 1) / rpp, 2048);
+    ProfScope ps("sk16_first_fwd", st);
+    if (d <= 8) launch_k(ps, sk_first_fwd_kernel<8>, dim3(grid), dim3(256), 0, st, a);
+    else launch_k(ps, sk_first_fwd_kernel<16>, dim3(grid), dim3(256), 0, st, a);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+static int sk_rows(const SkRowsArgs& a, int epi, const char* label, hipStream_t st) {
+    const unsigned grid = (unsigned)((a.M + 127) / 128);
+    ProfScope ps(label, st);
+    if (epi == SK_PLAIN) launch_k(ps, sk_rows_mfma_kernel<SK_PLAIN>, dim3(grid), dim3(256), 0, st, a);
+    else if (epi == SK_REPARAM) launch_k(ps, sk_rows_mfma_kernel<SK_REPARAM>, dim3(grid), dim3(256), 0, st, a);
+    else launch_k(ps, sk_rows_mfma_kernel<SK_ELBO>, dim3(grid), dim3(256), 0, st, a);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+int launch_sk_last_fwd(const __bf16* h, const __bf16* wp, const float* b, float* y, int rows, int H, int d, hipStream_t st) {
+    SkRowsArgs a{};
+    a.A = h; a.Bt = wp; a.M = rows; a.K = H; a.d = d; a.lda = H; a.C = y; a.ldc = d; a.bias = b;
+    return sk_rows(a, SK_PLAIN, "sk16_last_fwd", st);
+}
+int launch_sk_last_fwd_reparam(const __bf16* h, const __bf16* wp, const float* b, float* mu, float* samples, const float* z1,
+                               const float* lv, int rows, int H, int d, hipStream_t st) {
+    SkRowsArgs a{};
+    a.A = h; a.Bt = wp; a.M = rows; a.K = H; a.d = d; a.lda = H; a.C = mu; a.ldc = d; a.bias = b; a.C2 = samples; a.z1 = z1; a.lv = lv;
+    return sk_rows(a, SK_REPARAM, "sk16_last_fwd_reparam", st);
+}
+int launch_sk_last_fwd_elbo(const __bf16* h, const __bf16* wp, const float* b, float* d_out, const float* x, const float* z2,
+                            const float* eps_param, float eps_cli, float inv_bt, float* part, int rows, int H, int d, int* bm,
+                            int* nbx, hipStream_t st) {
+    SkRowsArgs a{};
+    a.A = h; a.Bt = wp; a.M = rows; a.K = H; a.d = d; a.lda = H; a.C = d_out; a.ldc = d; a.bias = b;
+    a.x = x; a.z2 = z2; a.eps_param = eps_param; a.eps_cli = eps_cli; a.inv_bt = inv_bt; a.part = part;
+    *bm = 128; *nbx = 1;
+    return sk_rows(a, SK_ELBO, "sk16_last_fwd_elbo", st);
+}
+// first layer dX (the decoder's first layer): dx[rows, d] (+)= dY[rows, H] . W^T, W [d, H] padded to wp [32, H]
+int launch_sk_first_dx(const __bf16* dy, const __bf16* wp, float* dx, int rows, int H, int d, bool accumulate, hipStream_t st) {
+    SkRowsArgs a{};
+    a.A = dy; a.Bt = wp; a.M = rows; a.K = H; a.d = d; a.lda = H; a.C = dx; a.ldc = d; a.accumulate = accumulate ? 1 : 0;
+    return sk_rows(a, SK_PLAIN, "sk16_first_dx", st);
+}
+
+constexpr int kSkGroup = 64;       // partial images summed into one slab
+
+// S slabs <- S * 64 workgroups; rows_per_wg = ceil(rows / (S * 64))
+static int sk_reduce(const float* partial, long long n, int S, float* slab0, int64_t slab_stride, hipStream_t st) {
+    ProfScope ps("sk16_partials_reduce", st);
+    launch_k(ps, sk_partials_reduce_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)S), dim3(256), 0, st, partial, n, kSkGroup,
+             slab0, (long long)slab_stride);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+size_t sk_partial_bytes(int d, int H, int S) { return (size_t)S * kSkGroup * (size_t)std::max((H + 1) * d, (d + 1) * H) * sizeof(float); }
+
+int launch_sk_last_bwd(const __bf16* h, const float* dy, const float* w, __bf16* dh, float* partial, float* slab0, int64_t slab_stride,
+                       int S, int rows, int H, int d, hipStream_t st) {
+    const int nwg = S * kSkGroup;
+    SkBwdArgs a{h, dy, w, dh, partial, rows, d, H, (rows + nwg - 1) / nwg};
+    const int cprw = H / 8, rpp = 256 / cprw;
+    const size_t lds = (size_t)std::max(rpp - 1, 0) * cprw * (9 * d) * sizeof(float);
+    {
+        ProfScope ps("sk16_last_bwd", st);
+        if (d <= 8) {
+            static thread_local bool set8 = false;
+            if (!set8) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)sk_last_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set8 = true; }
+            launch_k(ps, sk_last_bwd_kernel<8>, dim3(nwg), dim3(256), lds, st, a);
+        } else {
+            static thread_local bool set16 = false;
+            if (!set16) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)sk_last_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set16 = true; }
+            launch_k(ps, sk_last_bwd_kernel<16>, dim3(nwg), dim3(256), lds, st, a);
+        }
+        VAEK_HIP_CHECK(hipGetLastError());
+    }
+    return sk_reduce(partial, (long long)(H + 1) * d, S, slab0, slab_stride, st);
+}
+
+int launch_sk_first_bwd(const float* x, const __bf16* dy, float* partial, float* slab0, int64_t slab_stride, int S, int rows, int H,
+                        int d, hipStream_t st) {
+    const int nwg = S * kSkGroup;
+    SkBwdArgs a{dy, x, nullptr, nullptr, partial, rows, d, H, (rows + nwg - 1) / nwg};
+    const int cprw = H / 8, rpp = 256 / cprw;
+    const size_t lds = (size_t)std::max(rpp - 1, 0) * cprw * ((d + 1) * 8) * sizeof(float);
+    {
+        ProfScope ps("sk16_first_bwd", st);
+        if (d <= 8) {
+            static thread_local bool set8 = false;
+            if (!set8) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)sk_first_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set8 = true; }
+            launch_k(ps, sk_first_bwd_kernel<8>, dim3(nwg), dim3(256), lds, st, a);
+        } else {
+            static thread_local bool set16 = false;
+            if (!set16) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)sk_first_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set16 = true; }
+            launch_k(ps, sk_first_bwd_kernel<16>, dim3(nwg), dim3(256), lds, st, a);
+        }
+        VAEK_HIP_CHECK(hipGetLastError());
+    }
+    return sk_reduce(partial, (long long)(d + 1) * H, S, slab0, slab_stride, st);
+}
+
+int launch_sk_prep(const float* params, __bf16* out, const int* H, const int* d, const int* transposed, const int64_t* w_off,
+                   const int64_t* out_off, int n, hipStream_t st) {
+    if (n <= 0) return VAEK_OK;
+    if (n > 16) { set_error("too many skinny layers"); return VAEK_ERR_INVALID; }
+    SkPrepArgs a{};
+    a.n = n;
+    for (int i = 0; i < n; ++i) { a.H[i] = H[i]; a.d[i] = d[i]; a.transposed[i] = transposed[i]; a.w_off[i] = w_off[i]; a.out_off[i] = out_off[i]; }
+    ProfScope ps("sk16_prep", st);
+    launch_k(ps, sk_prep_kernel, dim3(16, (unsigned)n), dim3(256), 0, st, params, out, a);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+}  // namespace vaek

@@ -35,6 +35,8 @@ struct Layer {
     int64_t w_off;    // kernel offset in the flat buffers; bias follows at w_off + n_in*n_out
     bool relu;        // relu after this layer (every layer but the last, networks.py:35-39)
     int S, rows_per_split;   // batch split of this layer's dW|db GEMM (skinny layers get more, smaller splits)
+    bool sk = false;         // first / last layer of a bf16-storage stack on the skinny kernels (gemm_skinny16.hip)
+    int64_t sk_off = 0;      // element offset of its padded bf16 kernel copy in ws_sk16
 };
 
 struct Net {
@@ -100,7 +102,7 @@ struct vaek_ctx {
     int S, rows_per_split, Se, rows_per_esplit;
     bool fused;                      // fused small-model path available and selected
     // workspace layout (bytes)
-    size_t ws_samples, ws_dsamp, ws_gbuf0, ws_gbuf1, ws_slabs, ws_epart, ws_rpart, ws_eblk, ws_fused, ws_wb16, ws_total;
+    size_t ws_samples, ws_dsamp, ws_gbuf0, ws_gbuf1, ws_slabs, ws_epart, ws_rpart, ws_eblk, ws_fused, ws_wb16, ws_sk16, ws_skpart, ws_total;
     int max_width;
     int n_cu;
     vaek::Comm comm;
@@ -161,6 +163,24 @@ int launch_hs_dw(const __bf16* x, const __bf16* dy, float* slab0, int64_t slab_s
                  int n_in, int n_out, hipStream_t st);
 int launch_cvt_weights(const float* params, __bf16* out, const int* K, const int* N, const int64_t* w_off, const int64_t* out_off,
                        int n, hipStream_t st);
+
+// gemm_skinny16.hip: first (d -> H) / last (H -> d) layer of a bf16-storage stack, d <= 16: one HBM pass per big tensor
+bool sk_supported(int d, int H);
+size_t sk_partial_bytes(int d, int H, int S);
+int launch_sk_first_fwd(const float* x, const float* w, const float* b, __bf16* y, int rows, int d, int H, bool relu, hipStream_t st);
+int launch_sk_last_fwd(const __bf16* h, const __bf16* wp, const float* b, float* y, int rows, int H, int d, hipStream_t st);
+int launch_sk_last_fwd_reparam(const __bf16* h, const __bf16* wp, const float* b, float* mu, float* samples, const float* z1,
+                               const float* lv, int rows, int H, int d, hipStream_t st);
+int launch_sk_last_fwd_elbo(const __bf16* h, const __bf16* wp, const float* b, float* d_out, const float* x, const float* z2,
+                            const float* eps_param, float eps_cli, float inv_bt, float* part, int rows, int H, int d, int* bm,
+                            int* nbx, hipStream_t st);
+int launch_sk_first_dx(const __bf16* dy, const __bf16* wp, float* dx, int rows, int H, int d, bool accumulate, hipStream_t st);
+int launch_sk_last_bwd(const __bf16* h, const float* dy, const float* w, __bf16* dh, float* partial, float* slab0, int64_t slab_stride,
+                       int S, int rows, int H, int d, hipStream_t st);
+int launch_sk_first_bwd(const float* x, const __bf16* dy, float* partial, float* slab0, int64_t slab_stride, int S, int rows, int H,
+                        int d, hipStream_t st);
+int launch_sk_prep(const float* params, __bf16* out, const int* H, const int* d, const int* transposed, const int64_t* w_off,
+                   const int64_t* out_off, int n, hipStream_t st);
 
 // ---- elbo.hip -----------------------------------------------------------------------------
 struct ElboArgs {
