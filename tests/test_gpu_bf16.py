@@ -64,3 +64,39 @@ def test_bf16_train_steps_reduce_loss():
         eng.train_step(params, grads, m, v, step, dev(sampler(rng, B)), dev(z[:, :6]), dev(z[:, 6:]), lr)
         losses.append(float(grads[eng.P]))
     assert np.isfinite(losses).all() and np.mean(losses[-5:]) < np.mean(losses[:5])
+
+
+def test_bf16s_variants_are_bitwise_identical():
+    """Every tile / ring variant of the bf16-storage GEMMs (csrc/gemm_bf16s.hip: 128- and 256-wide tiles, 2- to 6-deep LDS
+    rings, the persistent staggered form) accumulates the same k order, so the whole gradient must be BITWISE the default's --
+    which the tests above hold to the oracle.  4 096 rows for all of them; 65 536 rows (tiles > workgroups: the persistent
+    kernel crosses tile seams with loads in flight) for the persistent form."""
+    import ctypes as C
+    cfg = O.Config(6, 6, (256, 512, 256), (256, 256), -3.0, True, "sphere")
+    n_nt, n_tn = C.c_int(), C.c_int()
+    for B, nts in ((4096, None), (65536, (7, 11))):
+        p, x, z1, z2 = random_problem(cfg, dict(name="sphere", seed=69, dd=3, pad=3), B)
+        eng = engine_for(cfg, B, dtype="bf16")
+        lib = eng.lib
+        assert lib.vaek_debug_hs_variant(-2, 0, C.byref(n_nt), C.byref(n_tn)) == 0
+        params, xd, z1d, z2d = dev(O.flatten(cfg, p)), dev(x), dev(z1), dev(z2)
+        step = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+        def grads():
+            g = eng.new_flat(eng.grad_len)
+            eng.grads_only(params, g, step, xd, z1d, z2d)
+            torch.cuda.synchronize()
+            return g
+        try:
+            ref = grads()
+            assert torch.isfinite(ref).all()
+            for nt in (range(n_nt.value) if nts is None else nts):
+                assert lib.vaek_debug_hs_variant(nt, 0, None, None) == 0
+                assert torch.equal(grads(), ref), f"NT variant {nt} differs at B={B}"
+            assert lib.vaek_debug_hs_variant(-2, 0, None, None) == 0
+            if nts is None:
+                for tn in range(n_tn.value):
+                    assert lib.vaek_debug_hs_variant(-1, tn, None, None) == 0
+                    assert torch.equal(grads(), ref), f"TN variant {tn} differs"
+        finally:
+            lib.vaek_debug_hs_variant(-2, 0, None, None)

@@ -632,13 +632,17 @@ static const HsTnVariant kTn[] = {
     {hs_tn_kernel<32, 3>, 3 * 2 * 32 * 256, "128x128x32 ring3"},      // 4: three workgroups per CU
 };
 constexpr int kTnCount = sizeof(kTn) / sizeof(kTn[0]);
-int g_hs_variant_nt = 1, g_hs_variant_tn = 1;
+// -1 = by shape: 256 x 256 tiles where they still give every CU a workgroup (C3 at full size: forward 50 -> 44 us), 128 x 128
+// with three workgroups per CU otherwise; measured on the box (tools/hs_tune.py), every variant bitwise identical
+// (tests/test_gpu_bf16.py::test_bf16s_variants_are_bitwise_identical)
+int g_hs_variant_nt = -1, g_hs_variant_tn = 0;
 
 template <int EPI>
 static int hs_launch_nt(const HsArgs& g, const char* label, hipStream_t st) {
     if (g.M <= 0) return VAEK_OK;
     if (g.K % 64 || g.N % 64 || g.lda % 8 || g.ldb % 8 || g.ldc % 8) { set_error("bf16-storage GEMM needs widths that are multiples of 64"); return VAEK_ERR_INVALID; }
-    const int vi = g_hs_variant_nt;
+    const bool big = (long long)((g.M + 255) / 256) * ((g.N + 255) / 256) >= 256;
+    const int vi = g_hs_variant_nt >= 0 ? g_hs_variant_nt : (big ? 7 : 6);
     if (vi < 0 || vi >= kNtCount) { set_error("unknown bf16-storage GEMM variant %d", vi); return VAEK_ERR_INVALID; }
     const HsNtVariant& v = kNt[vi];
     const HsNtKernel fn = EPI == HS_FWD ? v.fwd : v.dx;
@@ -716,6 +720,7 @@ int launch_cvt_weights(const float* params, __bf16* out, const int* K, const int
 extern "C" int vaek_debug_hs_variant(int nt, int tn, int* n_nt, int* n_tn) {
     if (nt >= vaek::kNtCount || tn >= vaek::kTnCount) return VAEK_ERR_INVALID;
     if (nt >= 0) vaek::g_hs_variant_nt = nt;
+    if (nt == -2) vaek::g_hs_variant_nt = -1;            // back to the by-shape default
     if (tn >= 0) vaek::g_hs_variant_tn = tn;
     if (n_nt) *n_nt = vaek::kNtCount;
     if (n_tn) *n_tn = vaek::kTnCount;

@@ -26,6 +26,7 @@ namespace vaek {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 __device__ __forceinline__ unsigned sk_pack(float lo, float hi) {
     const bf16x2 v = {(__bf16)lo, (__bf16)hi};
@@ -60,21 +61,32 @@ __global__ __launch_bounds__(256) void sk_first_fwd_kernel(const SkFwdArgs a) {
         b8[0] = lo.x; b8[1] = lo.y; b8[2] = lo.z; b8[3] = lo.w; b8[4] = hi.x; b8[5] = hi.y; b8[6] = hi.z; b8[7] = hi.w;
     }
     const float floor_v = a.relu ? 0.f : -__builtin_huge_valf();
-    for (long long row = (long long)blockIdx.x * rpp + rsub; row < a.rows; row += (long long)gridDim.x * rpp) {
-        float xi[DMAX];
+    constexpr int U = 4;                                  // rows per trip: all x loads first
+    const long long stride = (long long)gridDim.x * rpp;
+    for (long long row = (long long)blockIdx.x * rpp + rsub; row < a.rows; row += U * stride) {
+        float xi[U][DMAX];
 #pragma unroll
-        for (int i = 0; i < DMAX; ++i) xi[i] = a.x[row * a.d + min(i, a.d - 1)];       // rows i >= d meet zero weights
-        float o[8];
+        for (int u = 0; u < U; ++u) {
+            const long long rr = min(row + u * stride, (long long)a.rows - 1);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = b8[j];
+            for (int i = 0; i < DMAX; ++i) xi[u][i] = a.x[rr * a.d + min(i, a.d - 1)];   // rows i >= d meet zero weights
+        }
 #pragma unroll
-        for (int i = 0; i < DMAX; ++i)
+        for (int u = 0; u < U; ++u) {
+            const long long rr = row + u * stride;
+            float o[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = fmaf(xi[i], w[i][j], o[j]);
+            for (int j = 0; j < 8; ++j) o[j] = b8[j];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], floor_v);
-        *reinterpret_cast<uint4*>(a.y + row * a.H + 8 * chunk) =
-            make_uint4(sk_pack(o[0], o[1]), sk_pack(o[2], o[3]), sk_pack(o[4], o[5]), sk_pack(o[6], o[7]));
+            for (int i = 0; i < DMAX; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = fmaf(xi[u][i], w[i][j], o[j]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], floor_v);
+            if (rr < a.rows)
+                *reinterpret_cast<uint4*>(a.y + rr * a.H + 8 * chunk) =
+                    make_uint4(sk_pack(o[0], o[1]), sk_pack(o[2], o[3]), sk_pack(o[4], o[5]), sk_pack(o[6], o[7]));
+        }
     }
 }
 
@@ -164,37 +176,56 @@ __global__ __launch_bounds__(256) void sk_last_bwd_kernel(const SkBwdArgs a) {
     const int cprw = a.H >> 3, rpp = 256 / cprw, t = threadIdx.x;
     const bool active = t < rpp * cprw;
     const int chunk = active ? t % cprw : 0, rsub = active ? t / cprw : 0;
-    float w[8][DMAX], g[8][DMAX], gb[DMAX];
+    // pairs of latent / data columns as float2: v_pk_fma_f32 does two of this kernel's ~130 FMAs per row and lane at once
+    // (it is VALU-, not HBM-bound: 216 vector instructions per KB of h)
+    constexpr int DP = DMAX / 2;
+    f32x2 w[8][DP], g[8][DP], gb[DP];
 #pragma unroll
     for (int j = 0; j < 8; ++j)
 #pragma unroll
         for (int n = 0; n < DMAX; ++n) {
             const float v = a.w[(long long)(8 * chunk + j) * a.d + min(n, a.d - 1)];
-            w[j][n] = n < a.d ? v : 0.f;
-            g[j][n] = 0.f;
+            w[j][n >> 1][n & 1] = n < a.d ? v : 0.f;
+            g[j][n >> 1][n & 1] = 0.f;
         }
 #pragma unroll
-    for (int n = 0; n < DMAX; ++n) gb[n] = 0.f;
+    for (int n = 0; n < DP; ++n) gb[n] = f32x2{0.f, 0.f};
     const long long r0 = (long long)blockIdx.x * a.rows_per_wg, r1 = min((long long)a.rows, r0 + a.rows_per_wg);
+    // U rows per trip, every load of the trip issued before the first use (unconditional, clamped row; the surplus rows of the
+    // last trip are masked out of the sums and not stored): one row per trip was one exposed HBM round trip per KB and wave
+    constexpr int U = 4;
     if (active)
-        for (long long row = r0 + rsub; row < r1; row += rpp) {
-            const uint4 hv = *reinterpret_cast<const uint4*>(a.big + row * a.H + 8 * chunk);
-            float dyv[DMAX];
+        for (long long row = r0 + rsub; row < r1; row += (long long)U * rpp) {
+            uint4 hv[U]; f32x2 dyv[U][DP];
 #pragma unroll
-            for (int n = 0; n < DMAX; ++n) { const float v = a.small[row * a.d + min(n, a.d - 1)]; dyv[n] = n < a.d ? v : 0.f; }
-            float hf[8], o[8];
-            sk_unpack8(hv, hf);
+            for (int u = 0; u < U; ++u) {
+                const long long rr = min(row + (long long)u * rpp, r1 - 1);
+                hv[u] = *reinterpret_cast<const uint4*>(a.big + rr * a.H + 8 * chunk);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float s = 0.f;
-#pragma unroll
-                for (int n = 0; n < DMAX; ++n) { s = fmaf(dyv[n], w[j][n], s); g[j][n] = fmaf(hf[j], dyv[n], g[j][n]); }
-                o[j] = hf[j] > 0.f ? s : 0.f;                                  // relu'
+                for (int n = 0; n < DMAX; ++n) dyv[u][n >> 1][n & 1] = a.small[rr * a.d + min(n, a.d - 1)];
             }
 #pragma unroll
-            for (int n = 0; n < DMAX; ++n) gb[n] += dyv[n];
-            *reinterpret_cast<uint4*>(a.dh + row * a.H + 8 * chunk) =
-                make_uint4(sk_pack(o[0], o[1]), sk_pack(o[2], o[3]), sk_pack(o[4], o[5]), sk_pack(o[6], o[7]));
+            for (int u = 0; u < U; ++u) {
+                const long long rr = row + (long long)u * rpp;
+                const bool in = rr < r1;
+                float hf[8], o[8];
+                sk_unpack8(hv[u], hf);
+#pragma unroll
+                for (int n = 0; n < DMAX; ++n) dyv[u][n >> 1][n & 1] = (in && n < a.d) ? dyv[u][n >> 1][n & 1] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    f32x2 s2 = {0.f, 0.f};
+                    const f32x2 hj = {hf[j], hf[j]};
+#pragma unroll
+                    for (int n = 0; n < DP; ++n) { s2 = dyv[u][n] * w[j][n] + s2; g[j][n] = hj * dyv[u][n] + g[j][n]; }
+                    o[j] = hf[j] > 0.f ? s2[0] + s2[1] : 0.f;                  // relu'
+                }
+#pragma unroll
+                for (int n = 0; n < DP; ++n) gb[n] += dyv[u][n];
+                if (in)
+                    *reinterpret_cast<uint4*>(a.dh + rr * a.H + 8 * chunk) =
+                        make_uint4(sk_pack(o[0], o[1]), sk_pack(o[2], o[3]), sk_pack(o[4], o[5]), sk_pack(o[6], o[7]));
+            }
         }
     // the rpp row phases of a column chunk: phases 1.. park their sums in LDS, phase 0 adds them in order
     const int per = 8 * a.d + a.d;                          // floats a thread contributes: its 8 x d block, then gb
@@ -203,9 +234,9 @@ __global__ __launch_bounds__(256) void sk_last_bwd_kernel(const SkBwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int n = 0; n < DMAX; ++n) if (n < a.d) p[j * a.d + n] = g[j][n];
+            for (int n = 0; n < DMAX; ++n) if (n < a.d) p[j * a.d + n] = g[j][n >> 1][n & 1];
 #pragma unroll
-        for (int n = 0; n < DMAX; ++n) if (n < a.d) p[8 * a.d + n] = gb[n];
+        for (int n = 0; n < DMAX; ++n) if (n < a.d) p[8 * a.d + n] = gb[n >> 1][n & 1];
     }
     __syncthreads();
     if (active && rsub == 0) {
@@ -214,18 +245,18 @@ __global__ __launch_bounds__(256) void sk_last_bwd_kernel(const SkBwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
 #pragma unroll
-                for (int n = 0; n < DMAX; ++n) if (n < a.d) g[j][n] += p[j * a.d + n];
+                for (int n = 0; n < DMAX; ++n) if (n < a.d) g[j][n >> 1][n & 1] += p[j * a.d + n];
 #pragma unroll
-            for (int n = 0; n < DMAX; ++n) if (n < a.d) gb[n] += p[8 * a.d + n];
+            for (int n = 0; n < DMAX; ++n) if (n < a.d) gb[n >> 1][n & 1] += p[8 * a.d + n];
         }
         float* out = a.partial + (long long)blockIdx.x * ((long long)(a.H + 1) * a.d);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int n = 0; n < DMAX; ++n) if (n < a.d) out[(long long)(8 * chunk + j) * a.d + n] = g[j][n];
+            for (int n = 0; n < DMAX; ++n) if (n < a.d) out[(long long)(8 * chunk + j) * a.d + n] = g[j][n >> 1][n & 1];
         if (chunk == 0) {
 #pragma unroll
-            for (int n = 0; n < DMAX; ++n) if (n < a.d) out[(long long)a.H * a.d + n] = gb[n];
+            for (int n = 0; n < DMAX; ++n) if (n < a.d) out[(long long)a.H * a.d + n] = gb[n >> 1][n & 1];
         }
     }
 }
@@ -237,24 +268,37 @@ __global__ __launch_bounds__(256) void sk_first_bwd_kernel(const SkBwdArgs a) {
     const int cprw = a.H >> 3, rpp = 256 / cprw, t = threadIdx.x;
     const bool active = t < rpp * cprw;
     const int chunk = active ? t % cprw : 0, rsub = active ? t / cprw : 0;
-    float g[DMAX + 1][8];
+    f32x2 g[DMAX + 1][4];               // column pairs as float2 (v_pk_fma_f32)
 #pragma unroll
     for (int i = 0; i <= DMAX; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g[i][j] = 0.f;
+        for (int j = 0; j < 4; ++j) g[i][j] = f32x2{0.f, 0.f};
     const long long r0 = (long long)blockIdx.x * a.rows_per_wg, r1 = min((long long)a.rows, r0 + a.rows_per_wg);
+    constexpr int U = 4;                                  // rows per trip, loads first (see sk_last_bwd_kernel)
     if (active)
-        for (long long row = r0 + rsub; row < r1; row += rpp) {
-            const uint4 dv = *reinterpret_cast<const uint4*>(a.big + row * a.H + 8 * chunk);
-            float xi[DMAX], df[8];
+        for (long long row = r0 + rsub; row < r1; row += (long long)U * rpp) {
+            uint4 dv[U]; float xi[U][DMAX];
 #pragma unroll
-            for (int i = 0; i < DMAX; ++i) { const float v = a.small[row * a.d + min(i, a.d - 1)]; xi[i] = i < a.d ? v : 0.f; }
-            sk_unpack8(dv, df);
+            for (int u = 0; u < U; ++u) {
+                const long long rr = min(row + (long long)u * rpp, r1 - 1);
+                dv[u] = *reinterpret_cast<const uint4*>(a.big + rr * a.H + 8 * chunk);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+                for (int i = 0; i < DMAX; ++i) xi[u][i] = a.small[rr * a.d + min(i, a.d - 1)];
+            }
 #pragma unroll
-                for (int i = 0; i < DMAX; ++i) g[i][j] = fmaf(xi[i], df[j], g[i][j]);
-                g[DMAX][j] += df[j];                                          // the ones row of [x | 1]^T dY
+            for (int u = 0; u < U; ++u) {
+                const bool in = row + (long long)u * rpp < r1;
+                float df[8];
+                sk_unpack8(dv[u], df);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) df[j] = in ? df[j] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2 d2 = {df[2 * j], df[2 * j + 1]};
+#pragma unroll
+                    for (int i = 0; i < DMAX; ++i) { const float xv = i < a.d ? xi[u][i] : 0.f; g[i][j] = f32x2{xv, xv} * d2 + g[i][j]; }
+                    g[DMAX][j] += d2;                                         // the ones row of [x | 1]^T dY
+                }
             }
         }
     const int per = (a.d + 1) * 8;
@@ -263,9 +307,9 @@ __global__ __launch_bounds__(256) void sk_first_bwd_kernel(const SkBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < DMAX; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) if (i < a.d) p[i * 8 + j] = g[i][j];
+            for (int j = 0; j < 8; ++j) if (i < a.d) p[i * 8 + j] = g[i][j >> 1][j & 1];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) p[a.d * 8 + j] = g[DMAX][j];
+        for (int j = 0; j < 8; ++j) p[a.d * 8 + j] = g[DMAX][j >> 1][j & 1];
     }
     __syncthreads();
     if (active && rsub == 0) {
@@ -274,19 +318,19 @@ __global__ __launch_bounds__(256) void sk_first_bwd_kernel(const SkBwdArgs a) {
 #pragma unroll
             for (int i = 0; i < DMAX; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) if (i < a.d) g[i][j] += p[i * 8 + j];
+                for (int j = 0; j < 8; ++j) if (i < a.d) g[i][j >> 1][j & 1] += p[i * 8 + j];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g[DMAX][j] += p[a.d * 8 + j];
+            for (int j = 0; j < 8; ++j) g[DMAX][j >> 1][j & 1] += p[a.d * 8 + j];
         }
         float* out = a.partial + (long long)blockIdx.x * ((long long)(a.d + 1) * a.H);
 #pragma unroll
         for (int i = 0; i < DMAX; ++i)
             if (i < a.d) {
-                *reinterpret_cast<float4*>(out + (long long)i * a.H + 8 * chunk) = make_float4(g[i][0], g[i][1], g[i][2], g[i][3]);
-                *reinterpret_cast<float4*>(out + (long long)i * a.H + 8 * chunk + 4) = make_float4(g[i][4], g[i][5], g[i][6], g[i][7]);
+                *reinterpret_cast<float4*>(out + (long long)i * a.H + 8 * chunk) = make_float4(g[i][0][0], g[i][0][1], g[i][1][0], g[i][1][1]);
+                *reinterpret_cast<float4*>(out + (long long)i * a.H + 8 * chunk + 4) = make_float4(g[i][2][0], g[i][2][1], g[i][3][0], g[i][3][1]);
             }
-        *reinterpret_cast<float4*>(out + (long long)a.d * a.H + 8 * chunk) = make_float4(g[DMAX][0], g[DMAX][1], g[DMAX][2], g[DMAX][3]);
-        *reinterpret_cast<float4*>(out + (long long)a.d * a.H + 8 * chunk + 4) = make_float4(g[DMAX][4], g[DMAX][5], g[DMAX][6], g[DMAX][7]);
+        *reinterpret_cast<float4*>(out + (long long)a.d * a.H + 8 * chunk) = make_float4(g[DMAX][0][0], g[DMAX][0][1], g[DMAX][1][0], g[DMAX][1][1]);
+        *reinterpret_cast<float4*>(out + (long long)a.d * a.H + 8 * chunk + 4) = make_float4(g[DMAX][2][0], g[DMAX][2][1], g[DMAX][3][0], g[DMAX][3][1]);
     }
 }
 
