@@ -236,6 +236,9 @@ def main():
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a ONE-GPU box: every rank uses cuda:0 and the process group is gloo")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="Dense GEMM arithmetic (bf16: wide layers on bf16 MFMA)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="linear VAEs on one GPU: the step-by-step kernels (vaek_train_step) instead of vaek_train_steps, the N-step "
+                         "entry point whose launches overlap the pass over batch n + 2 with the Adam update of batch n")
     ap.add_argument("--graph", type=int, default=-1,
                     help="steps captured per hipGraph (0 = eager launches; -1 = auto: the largest even size <= 200 dividing --steps)")
     args = ap.parse_args()
@@ -297,6 +300,22 @@ def main():
             exch.overlapped_grads(params, grads, step_dev, x, z1, z2)
             eng.apply(params, grads, m, v, step_dev, lr)
 
+    # Linear VAE on one GPU (the metric's workload): K consecutive steps go through vaek_train_steps -- every step still
+    # reads its own batch once, computes loss and gradients at the CURRENT parameters and applies Adam, but evaluated through
+    # the batch's second-moment matrix, so that launch n streams batch n while it sums batch n - 1 and updates with batch n - 2
+    # (csrc/linear_moments.hip).  Everything else: one vaek_train_step per step.
+    use_pipe = exch is None and not args.no_pipeline and eng.supports_train_steps()
+
+    def run_group(i0, n):
+        """n consecutive train steps on batches i0, i0 + 1, ... (mod the rotation)."""
+        if n <= 0:
+            return
+        if use_pipe:
+            eng.train_steps(params, grads, m, v, step_dev, [batches[(i0 + k) % len(batches)] for k in range(n)], lr)
+        else:
+            for k in range(n):
+                one_step(i0 + k)
+
     def fence():
         if dist is not None:
             dist.barrier()
@@ -316,8 +335,7 @@ def main():
             gsteps = min(cands, key=lambda g: (args.steps % g, -g))          # fewest eager left-over steps, then the largest
     graph = None
     n_warm_eager = max(args.warmup, 3)
-    for i in range(n_warm_eager):
-        one_step(i)
+    run_group(0, n_warm_eager)
     if gsteps > 0:
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
@@ -325,8 +343,7 @@ def main():
         with torch.cuda.stream(side):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):
-                for i in range(gsteps):
-                    one_step(i)
+                run_group(0, gsteps)
         torch.cuda.current_stream().wait_stream(side)
         fence()                             # ranks leave capture at different times: line them up first
         graph.replay()                      # one untimed replay (graph upload)
@@ -337,8 +354,7 @@ def main():
             while n - done >= gsteps:
                 graph.replay()
                 done += gsteps
-        for i in range(n - done):
-            one_step(i)
+        run_group(0, n - done)
 
     def sweep():
         """Evict whatever the untimed steps left in the 256 MiB Infinity Cache, so that the timed steps read their inputs from
@@ -348,8 +364,7 @@ def main():
         if mall_sweep is None:
             return
         mall_sweep.fill_(1.0)
-        for i in range(4):
-            one_step(len(batches) - 1 - i)
+        run_group(len(batches) - 4, 4)
 
     sweep()
     fence()
@@ -372,8 +387,7 @@ def main():
         rsteps = min(args.steps, 192)                       # kernel-timestamp leg (one event pair per launch)
         sweep()
         eng.profile_begin(max_records=rsteps * 64)
-        for i in range(rsteps):
-            one_step(i)
+        run_group(0, rsteps)
         torch.cuda.synchronize()
         rep = eng.profile_report()
         if rep:
@@ -483,6 +497,7 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w['desc']}", "batch_per_gpu": B_local, "global_batch": B_global,
                        "data_dim": D, "latent_dim": L, "params": eng.P, "path": "fused" if eng.fused else "layer-by-layer",
+                       "step_entry_point": ("vaek_train_steps (N steps, software-pipelined over launches)" if use_pipe else "vaek_train_step"),
                        "parallelism": f"dp{world}", "grad_exchange": (exch.mode if exch else "none"),
                        "launch": (f"hipGraph x{gsteps} steps" if graph is not None else "eager"), "input_batches": nbuf,
                        "final_loss": loss},

@@ -215,6 +215,18 @@ int vaek_train_step_gen(vaek_ctx* ctx, float* params, float* grads, float* m, fl
                         const float* z1, const float* z2, float lr, void* workspace, int32_t kind, const float* A, int32_t dd,
                         int32_t did, int32_t pad, float var_added, float* x_next, float* z1_next, float* z2_next, int64_t row0,
                         uint64_t seed, int32_t* counter, int32_t which, uint32_t tag, void* stream);
+/* N consecutive VAE.train_step's (the loop body of model.py:221-222 -> networks.py:87-101, N times) on N batches already
+ * resident in HBM: xs / z1s / z2s are HOST arrays of n_steps device pointers (batch i = xs[i][B,D], z1s[i][B,L], z2s[i][B,D]).
+ * On return (in stream order) params / m / v / *step_dev / grads are what n_steps calls of vaek_train_step on those batches
+ * leave, to float32 summation-order tolerance -- NOT bitwise: the steps are evaluated through the batch's second-moment
+ * matrix (csrc/linear_moments.hip), which takes the parameters off the streaming pass, so that the pass over batch n + 2,
+ * the cross-workgroup sum of batch n + 1 and the Adam update of batch n run in ONE launch, synchronised by stream order
+ * alone (n_steps + 2 launches, capturable into a hipGraph).  Linear encoder / decoder, one decoder, float32, L + 2 D + 1 <= 64,
+ * single GPU: vaek_supports_train_steps says whether this context qualifies; others return VAEK_ERR_INVALID. */
+int vaek_supports_train_steps(const vaek_ctx* ctx, int32_t* yes);
+int vaek_train_steps(vaek_ctx* ctx, float* params, float* grads, float* m, float* v, int32_t* step_dev,
+                     const float* const* xs, const float* const* z1s, const float* const* z2s, int32_t n_steps, float lr,
+                     void* workspace, void* stream);
 /* n standard normals and/or the raw Philox words they came from (block b = counter (b_lo, b_hi, step, tag)). */
 int vaek_rng_fill(vaek_ctx* ctx, float* normals, uint32_t* bits, int64_t n, uint64_t seed, uint32_t step, uint32_t tag,
                   void* stream);

@@ -1,0 +1,110 @@
+"""-m gpu: vaek_train_steps -- N software-pipelined train steps of a linear VAE evaluated through the batch's second-moment
+matrix (csrc/linear_moments.hip) -- against the float64 oracle's N sequential VAE.train_step's (networks.py:87-101) on the
+same batches, and against the library's own step-by-step path (vaek_train_step).  Tolerances are the f32 path's: loss 1e-5
+relative (BASELINE's contract; measured ~1e-7), parameters within 2 % of one Adam step per step taken."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import elbo_oracle as O
+from tests.cases import build
+from tests.gpu_util import dev, engine_for, host
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(cfg, dk, B, n, seed=5):
+    _, sampler = O.make_dataset(**dk)
+    rng = np.random.default_rng(seed)
+    r32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    p = {k: r32(v) for k, v in O.init_params(cfg, seed=3).items()}
+    for k in p:
+        if not k.endswith("kernel"):
+            p[k] = r32(p[k] + 0.2 * rng.standard_normal(p[k].shape))
+    batches = []
+    for _ in range(n):
+        x = r32(sampler(rng, B))
+        z1, z2 = O.split_latents(r32(rng.standard_normal((B, cfg.L + cfg.D))), cfg.L)
+        batches.append((x, np.ascontiguousarray(z1), np.ascontiguousarray(z2)))
+    return p, batches
+
+
+def _run_pipelined(eng, cfg, p, batches, lr):
+    params = dev(O.flatten(cfg, p)); grads = eng.new_flat(eng.grad_len); m = eng.new_flat(); v = eng.new_flat()
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ring = torch.zeros(len(batches) + 8, dtype=torch.float32, device="cuda")
+    eng.set_loss_history(ring)
+    eng.train_steps(params, grads, m, v, step, [tuple(dev(a) for a in b) for b in batches], lr)
+    torch.cuda.synchronize()
+    eng.set_loss_history(None)
+    return params, grads, m, v, int(step.item()), host(ring)[:len(batches)]
+
+
+@pytest.mark.parametrize("name,B,n", [("c1_linear_L20", 16, 6), ("c1_linear_L2", 16, 6), ("linear_notdv", 8, 5),
+                                      ("c1_linear_L20", 1000, 7), ("c1_linear_L20", 256, 1), ("c1_linear_L2", 777, 2)])
+def test_pipelined_steps_match_the_oracle(name, B, n):
+    cfg, dk, _, lr = build(name)
+    p, batches = _problem(cfg, dk, B, n)
+    eng = engine_for(cfg, B)
+    assert eng.supports_train_steps()
+    params, grads, m, v, step, losses = _run_pipelined(eng, cfg, p, batches, lr)
+    st = O.adam_init(p)
+    for i, (x, z1, z2) in enumerate(batches):
+        p, st, loss = O.train_step(cfg, p, st, x, z1, z2, lr)
+        assert abs(losses[i] - loss) <= 1e-5 * abs(loss), (i, losses[i], loss)
+    assert step == n
+    assert abs(float(grads[eng.P]) - loss) <= 1e-5 * abs(loss)
+    assert np.max(np.abs(host(params) - O.flatten(cfg, p))) <= 0.02 * lr * n
+    wm, wv = O.flatten(cfg, st["m"]), O.flatten(cfg, st["v"])
+    assert np.max(np.abs(host(m) - wm)) <= 2e-5 * np.max(np.abs(wm)) + 1e-9
+    assert np.max(np.abs(host(v) - wv)) <= 5e-5 * np.max(np.abs(wv)) + 1e-12
+
+
+def test_three_hundred_pipelined_steps_stay_on_the_oracle_trajectory():
+    cfg, dk, _, lr = build("c1_linear_L20")
+    B, n = 1024, 300
+    p, batches = _problem(cfg, dk, B, n)
+    eng = engine_for(cfg, B)
+    params, grads, m, v, step, losses = _run_pipelined(eng, cfg, p, batches, lr)
+    st = O.adam_init(p)
+    want = []
+    for x, z1, z2 in batches:
+        p, st, loss = O.train_step(cfg, p, st, x, z1, z2, lr)
+        want.append(loss)
+    want = np.array(want)
+    assert step == n and np.max(np.abs(losses - want) / np.abs(want)) <= 1e-5
+    assert np.max(np.abs(host(params) - O.flatten(cfg, p))) <= 2e-5          # 300 steps of 1e-3: within 2 % of ONE step
+    assert want[-1] < want[0]
+
+
+def test_metric_size_and_agreement_with_the_step_by_step_kernels():
+    """B = 65 536 (the metric's batch): 4 pipelined steps vs the oracle, and vs vaek_train_step on the same batches (the two
+    library paths differ only in summation order)."""
+    cfg, dk, _, lr = build("c1_linear_L20")
+    B, n = 65536, 4
+    p0, batches = _problem(cfg, dk, B, n)
+    eng = engine_for(cfg, B)
+    params, grads, m, v, step, losses = _run_pipelined(eng, cfg, p0, batches, lr)
+    p, st = dict(p0), O.adam_init(p0)
+    for i, (x, z1, z2) in enumerate(batches):
+        p, st, loss = O.train_step(cfg, p, st, x, z1, z2, lr)
+        assert abs(losses[i] - loss) <= 1e-5 * abs(loss), (i, losses[i], loss)
+    assert np.max(np.abs(host(params) - O.flatten(cfg, p))) <= 0.02 * lr * n
+    p2 = dev(O.flatten(cfg, p0)); g2 = eng.new_flat(eng.grad_len); m2 = eng.new_flat(); v2 = eng.new_flat()
+    s2 = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for x, z1, z2 in batches:
+        eng.train_step(p2, g2, m2, v2, s2, dev(x), dev(z1), dev(z2), lr)
+    assert float((params - p2).abs().max()) <= 0.02 * lr and abs(float(grads[eng.P]) - float(g2[eng.P])) <= 1e-5 * abs(float(g2[eng.P]))
+
+
+def test_pipelined_steps_refuse_what_they_cannot_do():
+    from vae_training_amd._lib import VaekError
+    cfg = O.Config(7, 6, (), (), -3.0, True, "sigmoid")           # two decoders with a sigmoid head: not linear in the inputs
+    eng = engine_for(cfg, 64)
+    assert not eng.supports_train_steps()
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    with pytest.raises(VaekError):
+        eng.train_steps(eng.new_flat(), eng.new_flat(eng.grad_len), eng.new_flat(), eng.new_flat(),
+                        torch.zeros(1, dtype=torch.int32, device="cuda"), [(z(64, 7), z(64, 6), z(64, 7))], 1e-3)
+    mlp = engine_for(O.Config(12, 20, (32,), (32,), -1.0, True, "linear_gaussian"), 64)
+    assert not mlp.supports_train_steps()

@@ -458,6 +458,7 @@ int vaek_ctx_create(const vaek_config* cfg, vaek_ctx** out) {
     c->ws_wb16 = off; off = align_up(off + (size_t)wb_elems * sizeof(__bf16), 256);
     c->ws_sk16 = off; off = align_up(off + (size_t)sk_elems * sizeof(__bf16), 256);
     c->ws_skpart = off; off = align_up(off + sk_part, 256);
+    c->ws_lin = off; off = align_up(off + lin_steps_workspace_bytes(c), 256);
     c->ws_total = off;
     *out = c;
     return VAEK_OK;
@@ -656,6 +657,31 @@ int vaek_train_step_gen(vaek_ctx* ctx, float* params, float* grads, float* m, fl
     // layer-by-layer path: the same two operations as separate launches on the one stream
     if ((rc = make_batch_launch(ctx, gen, st))) return rc;
     return vaek_train_step(ctx, params, grads, m, v, step_dev, x, z1, z2, lr, workspace, stream);
+}
+
+int vaek_supports_train_steps(const vaek_ctx* ctx, int32_t* yes) {
+    if (!ctx || !yes) { set_error("null argument"); return VAEK_ERR_INVALID; }
+    *yes = lin_steps_supported(ctx) ? 1 : 0;
+    return VAEK_OK;
+}
+
+int vaek_train_steps(vaek_ctx* ctx, float* params, float* grads, float* m, float* v, int32_t* step_dev, const float* const* xs,
+                     const float* const* z1s, const float* const* z2s, int32_t n_steps, float lr, void* workspace, void* stream) {
+    ProfBind pb(ctx);
+    if (!ctx || !params || !grads || !m || !v || !step_dev || !xs || !z1s || !z2s || n_steps < 0) { set_error("vaek_train_steps: invalid argument"); return VAEK_ERR_INVALID; }
+    if (!lin_steps_supported(ctx)) {
+        set_error("vaek_train_steps: this context is not a single-GPU float32 linear VAE with L + 2 D + 1 <= 64 (use vaek_train_step)");
+        return VAEK_ERR_INVALID;
+    }
+    int rc = check_ws(ctx, workspace);
+    if (rc) return rc;
+    for (int i = 0; i < n_steps; ++i)
+        if (!xs[i] || !z1s[i] || !z2s[i] || ((reinterpret_cast<uintptr_t>(xs[i]) | reinterpret_cast<uintptr_t>(z1s[i]) | reinterpret_cast<uintptr_t>(z2s[i])) & 15)) {
+            set_error("vaek_train_steps: batch %d has a null or not 16-byte aligned pointer", i);
+            return VAEK_ERR_INVALID;
+        }
+    if (n_steps == 0) return VAEK_OK;
+    return lin_train_steps(ctx, params, grads, m, v, step_dev, xs, z1s, z2s, n_steps, lr, workspace, (hipStream_t)stream);
 }
 
 // buckets in the order the backward pass completes them: Decoder (last layer first), SigDecoder, Encoder, tail

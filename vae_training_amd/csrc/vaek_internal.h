@@ -102,7 +102,7 @@ struct vaek_ctx {
     int S, rows_per_split, Se, rows_per_esplit;
     bool fused;                      // fused small-model path available and selected
     // workspace layout (bytes)
-    size_t ws_samples, ws_dsamp, ws_gbuf0, ws_gbuf1, ws_slabs, ws_epart, ws_rpart, ws_eblk, ws_fused, ws_wb16, ws_sk16, ws_skpart, ws_total;
+    size_t ws_samples, ws_dsamp, ws_gbuf0, ws_gbuf1, ws_slabs, ws_epart, ws_rpart, ws_eblk, ws_fused, ws_wb16, ws_sk16, ws_skpart, ws_lin, ws_total;
     int max_width;
     int n_cu;
     vaek::Comm comm;
@@ -274,6 +274,12 @@ struct FusedArgs {
 };
 bool fused_mfma_supported(const vaek_ctx* c);
 int fused_mfma_launch(const vaek_ctx* c, const float* params, const void* fused_args, int grid, hipStream_t st);
+
+// ---- linear_moments.hip: N pipelined steps of a linear VAE through the batch's second-moment matrix --------------------
+bool lin_steps_supported(const vaek_ctx* c);
+size_t lin_steps_workspace_bytes(const vaek_ctx* c);
+int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v, int32_t* step_dev, const float* const* xs,
+                    const float* const* z1s, const float* const* z2s, int n_steps, float lr, void* ws, hipStream_t st);
 
 // ---- rng.hip ------------------------------------------------------------------------------
 // validates the arguments of vaek_make_batch* and fills `out`

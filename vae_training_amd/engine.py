@@ -122,6 +122,22 @@ class Engine:
                                                 _ptr(nxt[0]), _ptr(nxt[1]), _ptr(nxt[2]), int(row0), int(seed) & (2**64 - 1),
                                                 _ptr(counter), int(which), int(tag), _stream()))
 
+    def supports_train_steps(self):
+        f = C.c_int32()
+        _lib.check(self.lib.vaek_supports_train_steps(self.h, C.byref(f)))
+        return bool(f.value)
+
+    def train_steps(self, params, grads, m, v, step_dev, batches, lr):
+        """len(batches) consecutive train steps, batch i = (x, z1, z2) device tensors, software-pipelined over launches
+        (vaek_train_steps; linear VAEs only).  Asynchronous; capturable into a hipGraph."""
+        n = len(batches)
+        arr = lambda k: (C.c_void_p * n)(*[C.c_void_p(b[k].data_ptr()) for b in batches])
+        for b in batches:
+            assert all(t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 for t in b)
+        xs, z1s, z2s = arr(0), arr(1), arr(2)
+        _lib.check(self.lib.vaek_train_steps(self.h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(step_dev), xs, z1s, z2s, n,
+                                             float(lr), _ptr(self.workspace), _stream()))
+
     def grads_only(self, params, grads, step_dev, x, z1, z2):
         _lib.check(self.lib.vaek_train_step_grads_only(self.h, _ptr(params), _ptr(grads), _ptr(step_dev), _ptr(x),
                                                        _ptr(z1), _ptr(z2), _ptr(self.workspace), _stream()))
