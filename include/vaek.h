@@ -220,13 +220,17 @@ int vaek_train_step_gen(vaek_ctx* ctx, float* params, float* grads, float* m, fl
  * On return (in stream order) params / m / v / *step_dev / grads are what n_steps calls of vaek_train_step on those batches
  * leave, to float32 summation-order tolerance -- NOT bitwise: the steps are evaluated through the batch's second-moment
  * matrix (csrc/linear_moments.hip), which takes the parameters off the streaming pass, so that the pass over batch n + 2,
- * the cross-workgroup sum of batch n + 1 and the Adam update of batch n run in ONE launch, synchronised by stream order
- * alone (n_steps + 2 launches, capturable into a hipGraph).  Linear encoder / decoder, one decoder, float32, L + 2 D + 1 <= 64,
+ * the cross-workgroup sum of batch n + 1 and the Adam update of batch n run side by side -- as resident workgroup roles of one
+ * persistent launch per 64 steps (arrival counters, bounded waits: vaek_train_steps_status), or where that form does not apply as
+ * n_steps + 2 launches ordered by the stream alone.  Capturable into a hipGraph.  Linear encoder / decoder, one decoder, float32, L + 2 D + 1 <= 64,
  * single GPU: vaek_supports_train_steps says whether this context qualifies; others return VAEK_ERR_INVALID. */
 int vaek_supports_train_steps(const vaek_ctx* ctx, int32_t* yes);
 int vaek_train_steps(vaek_ctx* ctx, float* params, float* grads, float* m, float* v, int32_t* step_dev,
                      const float* const* xs, const float* const* z1s, const float* const* z2s, int32_t n_steps, float lr,
                      void* workspace, void* stream);
+/* Synchronous (reads one word back): *gave_up = 1 if a bounded in-launch wait of vaek_train_steps' persistent form ever expired
+ * (the results of that call are then invalid). */
+int vaek_train_steps_status(vaek_ctx* ctx, void* workspace, int32_t* gave_up);
 /* n standard normals and/or the raw Philox words they came from (block b = counter (b_lo, b_hi, step, tag)). */
 int vaek_rng_fill(vaek_ctx* ctx, float* normals, uint32_t* bits, int64_t n, uint64_t seed, uint32_t step, uint32_t tag,
                   void* stream);

@@ -37,6 +37,7 @@ def _run_pipelined(eng, cfg, p, batches, lr):
     eng.train_steps(params, grads, m, v, step, [tuple(dev(a) for a in b) for b in batches], lr)
     torch.cuda.synchronize()
     eng.set_loss_history(None)
+    assert not eng.train_steps_gave_up(), "a bounded in-launch wait of the persistent form expired"
     return params, grads, m, v, int(step.item()), host(ring)[:len(batches)]
 
 
@@ -108,3 +109,30 @@ def test_pipelined_steps_refuse_what_they_cannot_do():
                         torch.zeros(1, dtype=torch.int32, device="cuda"), [(z(64, 7), z(64, 6), z(64, 7))], 1e-3)
     mlp = engine_for(O.Config(12, 20, (32,), (32,), -1.0, True, "linear_gaussian"), 64)
     assert not mlp.supports_train_steps()
+
+
+def test_persistent_and_launch_per_step_forms_agree(monkeypatch):
+    """The two schedules of vaek_train_steps (one persistent launch per 64 steps with in-launch hand-offs; n + 2 launches ordered
+    by the stream) run the same arithmetic in the same order: bitwise equal parameters, moments and losses.  A subprocess takes
+    the launch-per-step form (the choice is read once per process)."""
+    import os, subprocess, sys, json
+    code = r"""
+import sys, json, numpy as np, torch
+sys.path.insert(0, %r)
+from oracle import elbo_oracle as O
+from tests.cases import build
+from tests.gpu_util import dev, engine_for
+from tests.test_gpu_steps import _problem, _run_pipelined
+cfg, dk, _, lr = build("c1_linear_L20")
+p, batches = _problem(cfg, dk, 3000, 70)
+eng = engine_for(cfg, 3000)
+params, grads, m, v, step, losses = _run_pipelined(eng, cfg, p, batches, lr)
+print(json.dumps({"p": params.cpu().numpy().view(np.int32).tolist(), "m": m.cpu().numpy().view(np.int32).tolist(), "l": np.asarray(losses, np.float32).view(np.int32).tolist()}))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for persist in ("1", "0"):
+        env = dict(os.environ, VAEK_LIN_PERSIST=persist)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1]

@@ -684,6 +684,14 @@ int vaek_train_steps(vaek_ctx* ctx, float* params, float* grads, float* m, float
     return lin_train_steps(ctx, params, grads, m, v, step_dev, xs, z1s, z2s, n_steps, lr, workspace, (hipStream_t)stream);
 }
 
+int vaek_train_steps_status(vaek_ctx* ctx, void* workspace, int32_t* gave_up) {
+    if (!ctx || !workspace || !gave_up) { set_error("null argument"); return VAEK_ERR_INVALID; }
+    int g = 0;
+    const int rc = lin_steps_status(ctx, workspace, &g);
+    *gave_up = g;
+    return rc;
+}
+
 // buckets in the order the backward pass completes them: Decoder (last layer first), SigDecoder, Encoder, tail
 static void bucket_list(const vaek_ctx* c, std::vector<std::pair<int64_t, int64_t>>& out) {
     out.clear();

@@ -25,8 +25,13 @@
 //     reducers    batch n-1: fixed-order float64 sum of the partial images -> M.
 //     updater     (one workgroup) batch n-2: the small dense algebra above in float64, the closed-form KL terms, the three
 //                 loss means, Adam (flax.optim.Adam.apply_gradient, networks.py:100), the step counter, the loss ring.
-// Stream order is the only synchronisation (no flags, no spins, nothing to dead-lock); the updater chain is the only thing
-// that is sequential in the parameters, and it is one workgroup's few microseconds.
+// In that launch-per-step form stream order is the only synchronisation.  The PERSISTENT form (default where it applies) runs
+// up to 64 steps in ONE launch with the same three roles as resident workgroups: streamers walk the batches with the tile of
+// batch n + 1 / n + 2 in flight while batch n is multiplied, reducers and the updater follow behind through per-batch arrival
+// counters (write-through partial images, one counter add per workgroup, relaxed polls: cdna guide G16 R1).  Every batch of
+// the launch has its OWN partial / M slot, so a streamer never waits for anybody: nothing can dead-lock, whatever the
+// dispatcher does with residency, and every poll is bounded (status word, vaek_train_steps_status).  What it buys on top:
+// no launch boundary and no cold start per step (the updater's instruction stream and parameters stay on one CU).
 //
 // Numerics: M accumulates exact-f32 products in chains of 64 samples (one wave's 16 MFMA k-steps), summed further in
 // float64; everything downstream is float64 until the final rounding of each gradient to float32.  Against the float64
@@ -42,16 +47,24 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
+constexpr int LNT = 512, LNW = LNT / 64;          // threads / waves per workgroup, every role
+constexpr int kLinMaxPersist = 64;                // steps per persistent launch (each owns a partial / M slot)
+constexpr int kLinReduceSets = 2;                 // persistent form: reducer sets taking alternate batches
+
 struct LinArgs {
     // roles by blockIdx.x: [0, has_update) the updater, then n_reduce reducers, then n_stream streamers
     int has_update, n_reduce, n_stream;
     int B, D, L, ntiles;
-    // streamers: the batch of this launch
+    // ---- launch-per-step form: streamers take THE batch of this launch, reducers the one before, the updater the one before that
     const float* x; const float* z1; const float* z2; float* partial_out;        // [ntiles][NBLK * 256]
-    // reducers: the batch of the previous launch
     const float* partial_in; double* M_out;                                       // [NBLK * 256]
-    // updater: the batch before that
     const double* M_in;
+    // ---- persistent form: n_steps batches, pointer tables in device memory, one slot per batch, arrival counters
+    int persistent, n_steps;
+    const float* const* xs; const float* const* z1s; const float* const* z2s;
+    float* partial_base; double* M_base;                                          // slot n at + n * ntiles * NO resp. + n * NO
+    unsigned* cnt_stream; unsigned* cnt_reduce; unsigned* status;                 // [n_steps], [n_steps], [1]; zeroed before the launch
+    // ---- updater
     float* params; float* grads; float* m; float* v; int32_t* step_dev; float lr;
     float inv_bt, eps_cli, rows, rows_over_bt; int off_eps, P;
     float* loss_hist; long long loss_hist_cap;
@@ -74,140 +87,157 @@ __device__ unsigned long long* g_lin_stamp_buf = nullptr;
 __device__ __forceinline__ void lin_glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((glb_void_t*)gsrc, (lds_void_t*)lds_wave_base, 16, 0, 0);
 }
+template <int N> __device__ __forceinline__ void lin_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // block (b1, b2), b1 <= b2, of the upper block triangle -> its index in the packed image
 __device__ __host__ constexpr int lin_blk(int NB, int b1, int b2) { return b1 * NB - b1 * (b1 - 1) / 2 + (b2 - b1); }
 
-constexpr int LNT = 1024, LNW = LNT / 64;          // threads / waves per workgroup, every role: the updater wants the latency hiding
+// write-through (sc1) accesses of the in-launch hand-offs: relaxed agent-scope atomics lower to global_store / global_load ... sc1
+__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// ---- streamer: M_tile = U^T U over this workgroup's 256 samples (16 per wave) ---------------------------------------------
-template <int NB>
-__device__ __forceinline__ void lin_stream(const LinArgs& a, char* smem, int tile) {
-    constexpr int NBLK = NB * (NB + 1) / 2;
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int D = a.D, L = a.L;
-    // LDS: the three tiles exactly as they lie in HBM (row-major [256][L] / [256][D]), each padded to whole 4 KB, then the
-    // validity column V[256] (the "1" feature; 0 for rows past the batch end) and a zero word
-    const int z1_bytes = (L * 1024 + 4095) / 4096 * 4096, x_bytes = (D * 1024 + 4095) / 4096 * 4096;
-    const int oX = z1_bytes, oZ2 = oX + x_bytes, oV = oZ2 + x_bytes, oC = oV + 1024;
+// All threads call; thread 0 polls `*cnt >= target` (relaxed, with s_sleep; bounded: ~2 s, then the status word is set and
+// every later wait of the launch returns at once so the grid drains), the workgroup barrier publishes the outcome.
+__device__ __forceinline__ void lin_wait_count(const unsigned* cnt, unsigned target, unsigned* status) {
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(8);
+            if ((++spins & 1023u) == 0 && (spins > (1u << 21) || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// ---- streamer pieces ------------------------------------------------------------------------------------------------------------
+// LDS slot of one 256-sample tile: the three tensors' tiles exactly as they lie in HBM (row-major [256][L] / [256][D]), each
+// padded to whole 8 KB (one pass of the 512-thread copy: every thread issues the same number of loads), the validity column
+// V[256] (the "1" feature; 0 for rows past the batch end) and a zero word.
+struct LinSlot {
+    int z1_b, x_b, oX, oZ2, oV, oC, bytes, passes;
+    __device__ __host__ LinSlot(int D, int L) {
+        z1_b = (L * 1024 + 8191) / 8192 * 8192; x_b = (D * 1024 + 8191) / 8192 * 8192;
+        oX = z1_b; oZ2 = oX + x_b; oV = oZ2 + x_b; oC = oV + 1024; bytes = (oC + 16 + 255) / 256 * 256;
+        passes = (z1_b + 2 * x_b) / 8192;
+    }
+};
+
+__device__ __forceinline__ void lin_issue_tile(const LinArgs& a, const LinSlot& sl, const float* x, const float* z1, const float* z2,
+                                               int tile, char* slot, int t, int wave) {
     const long long row0 = (long long)tile * 256;
     auto copy = [&](const float* src, int cols, int bytes, int lds_off) {
         const long long tot = (long long)a.B * cols * 4, base = row0 * cols * 4;
-        for (int i = 0; i * (LNT * 16) < bytes; ++i) {
-            const int local = i * (LNT * 16) + t * 16;           // a wave's 1 KB lies inside or outside the 4 KB-padded image as a whole
-            if (local >= bytes) continue;
-            long long off = base + local;
+        for (int i = 0; i < bytes / 8192; ++i) {
+            long long off = base + i * 8192 + t * 16;
             // a 16-byte piece that would run past the tensor's last whole 16 bytes: a valid, aligned address instead; what it
-            // brings lands in rows that are zeroed below -- or in the tensor's last <= 3 floats, which patch_tail() rewrites
+            // brings lands in rows that are zeroed afterwards -- or in the tensor's last <= 3 floats, which lin_fix_tile rewrites
             off = off + 16 <= (tot & ~15ll) ? off : ((tot & ~15ll) - 16);
-            lin_glds16(reinterpret_cast<const char*>(src) + off, smem + lds_off + i * (LNT * 16) + wave * 1024);
+            lin_glds16(reinterpret_cast<const char*>(src) + off, slot + lds_off + i * 8192 + wave * 1024);
         }
     };
-    // the floats behind the tensor's last whole 16 bytes (B * cols * 4 not a multiple of 16: e.g. L = 2 with an odd batch)
-    auto patch_tail = [&](const float* src, int cols, int lds_off) {
-        const long long tot = (long long)a.B * cols * 4, full = tot & ~15ll, base = row0 * cols * 4;
-        if (t < (int)((tot - full) / 4) && full >= base) reinterpret_cast<float*>(smem + lds_off)[(full - base) / 4 + t] = src[full / 4 + t];
-    };
-    copy(a.z1, L, z1_bytes, 0);
-    copy(a.x, D, x_bytes, oX);
-    copy(a.z2, D, x_bytes, oZ2);
-    const int valid = (int)min(256ll, (long long)a.B - row0);
-    if (t < 256) reinterpret_cast<float*>(smem + oV)[t] = t < valid ? 1.f : 0.f;
-    if (t == 0) *reinterpret_cast<float*>(smem + oC) = 0.f;
-    // per block: where this lane's feature 16 b + (lane & 15) lives (byte address of sample 0, byte stride per sample)
-    int fbase[NB], fstride[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int f = 16 * b + (lane & 15);
-        if (f < L) { fbase[b] = f * 4; fstride[b] = L * 4; }
-        else if (f < L + D) { fbase[b] = oX + (f - L) * 4; fstride[b] = D * 4; }
-        else if (f < L + 2 * D) { fbase[b] = oZ2 + (f - L - D) * 4; fstride[b] = D * 4; }
-        else if (f == L + 2 * D) { fbase[b] = oV; fstride[b] = 4; }
-        else { fbase[b] = oC; fstride[b] = 0; }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (valid < 256) {                                   // last tile of a ragged batch: rows past the end contribute nothing
-        patch_tail(a.z1, L, 0); patch_tail(a.x, D, oX); patch_tail(a.z2, D, oZ2);
-        for (int e = valid * L + t; e < 256 * L; e += LNT) reinterpret_cast<float*>(smem)[e] = 0.f;
-        for (int e = valid * D + t; e < 256 * D; e += LNT) { reinterpret_cast<float*>(smem + oX)[e] = 0.f; reinterpret_cast<float*>(smem + oZ2)[e] = 0.f; }
-        __syncthreads();
-    }
-    f32x4 acc[NBLK];
-#pragma unroll
-    for (int k = 0; k < NBLK; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // k-step s: lane group g = lane >> 4 takes sample 16 wave + s + 4 g.  The four samples of a step lie 4 rows apart: with 80- and
-    // 48-byte rows that is 16 banks, so the two lane groups ds_read_b32 services together never collide.
-    const int g = lane >> 4;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int sample = wave * 16 + s + 4 * g;
-        float op[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) op[b] = *reinterpret_cast<const float*>(smem + fbase[b] + sample * fstride[b]);
-#pragma unroll
-        for (int b1 = 0; b1 < NB; ++b1)
-#pragma unroll
-            for (int b2 = b1; b2 < NB; ++b2)
-                acc[lin_blk(NB, b1, b2)] = __builtin_amdgcn_mfma_f32_16x16x4f32(op[b1], op[b2], acc[lin_blk(NB, b1, b2)], 0, 0, 0);
-    }
-    __syncthreads();                                     // the input images are dead: reuse them for the waves' block images
-    float* R = reinterpret_cast<float*>(smem);
-    constexpr int NWR = NBLK <= 6 ? LNW : LNW / 2;         // images that fit LDS at once (16 x 6 KB = 96 KB; NB = 4 folds once first)
-    if (NWR < LNW) {
-        if (wave >= NWR) {
-#pragma unroll
-            for (int k = 0; k < NBLK; ++k)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) R[((wave - NWR) * NBLK + k) * 256 + (4 * g + r) * 16 + (lane & 15)] = acc[k][r];
-        }
-        __syncthreads();
-        if (wave < NWR) {
-#pragma unroll
-            for (int k = 0; k < NBLK; ++k)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[k][r] += R[(wave * NBLK + k) * 256 + (4 * g + r) * 16 + (lane & 15)];
-        }
-        __syncthreads();
-    }
-    if (wave < NWR) {
-#pragma unroll
-        for (int k = 0; k < NBLK; ++k)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) R[(wave * NBLK + k) * 256 + (4 * g + r) * 16 + (lane & 15)] = acc[k][r];   // row 4 g + r, column lane & 15
+    copy(z1, a.L, sl.z1_b, 0);
+    copy(x, a.D, sl.x_b, sl.oX);
+    copy(z2, a.D, sl.x_b, sl.oZ2);
+}
+
+// after the tile has landed: the validity column, the zero word, and for the last tile of a ragged batch the rows past the end
+__device__ __forceinline__ void lin_fix_tile(const LinArgs& a, const LinSlot& sl, const float* x, const float* z1, const float* z2,
+                                             int tile, char* slot, int t) {
+    const long long row0 = (long long)tile * 256;
+    const int valid = (int)min(256ll, (long long)a.B - row0), D = a.D, L = a.L;
+    if (t < 256) reinterpret_cast<float*>(slot + sl.oV)[t] = t < valid ? 1.f : 0.f;
+    if (t == 0) *reinterpret_cast<float*>(slot + sl.oC) = 0.f;
+    if (valid < 256) {
+        auto patch_tail = [&](const float* src, int cols, int lds_off) {     // floats behind the tensor's last whole 16 bytes
+            const long long tot = (long long)a.B * cols * 4, full = tot & ~15ll, base = row0 * cols * 4;
+            if (t < (int)((tot - full) / 4) && full >= base) reinterpret_cast<float*>(slot + lds_off)[(full - base) / 4 + t] = src[full / 4 + t];
+        };
+        patch_tail(z1, L, 0); patch_tail(x, D, sl.oX); patch_tail(z2, D, sl.oZ2);
+        for (int e = valid * L + t; e < 256 * L; e += LNT) reinterpret_cast<float*>(slot)[e] = 0.f;
+        for (int e = valid * D + t; e < 256 * D; e += LNT) { reinterpret_cast<float*>(slot + sl.oX)[e] = 0.f; reinterpret_cast<float*>(slot + sl.oZ2)[e] = 0.f; }
     }
     __syncthreads();
-    float* out = a.partial_out + (long long)tile * (NBLK * 256);
-    for (int o = t; o < NBLK * 256; o += LNT) {          // the waves' images in wave order
-        float sum = R[o];
+}
+
+// M_tile = U^T U.  The BLOCKS, not the samples, are dealt to the waves: wave w owns block w (of the upper block triangle) over
+// all 256 samples -- 64 k-steps of 4 samples, two accumulator chains -- so there is no cross-wave sum, no block images in LDS
+// and no barrier behind the products: the workgroup's whole LDS need is the tile itself (2 workgroups per CU: every role of
+// the persistent launch is resident at once).
+template <int NB, bool SC1>
+__device__ __forceinline__ void lin_multiply_tile(const LinArgs& a, const LinSlot& sl, const char* slot, float* out, int t, int wave) {
+    constexpr int NBLK = NB * (NB + 1) / 2;
+    const int lane = t & 63, g = lane >> 4, D = a.D, L = a.L;
+    for (int k = wave; k < NBLK; k += LNW) {
+        int b1 = 0, rem = k;
+        while (rem >= NB - b1) { rem -= NB - b1; ++b1; }
+        const int b2 = b1 + rem;
+        // where this lane's feature 16 b + (lane & 15) lives (byte offset of sample 0, byte stride per sample)
+        int fb[2], fs[2];
 #pragma unroll
-        for (int w = 1; w < NWR; ++w) sum += R[w * NBLK * 256 + o];
-        out[o] = sum;
+        for (int u = 0; u < 2; ++u) {
+            const int f = 16 * (u ? b2 : b1) + (lane & 15);
+            if (f < L) { fb[u] = f * 4; fs[u] = L * 4; }
+            else if (f < L + D) { fb[u] = sl.oX + (f - L) * 4; fs[u] = D * 4; }
+            else if (f < L + 2 * D) { fb[u] = sl.oZ2 + (f - L - D) * 4; fs[u] = D * 4; }
+            else if (f == L + 2 * D) { fb[u] = sl.oV; fs[u] = 4; }
+            else { fb[u] = sl.oC; fs[u] = 0; }
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // k-step (q, s): lane group g takes sample 16 q + s + 4 g.  The four samples of a step lie 4 rows apart: with 80- and 48-byte
+        // rows that is 16 banks, so the two lane groups ds_read_b32 services together never collide.
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            float oa[4], ob[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int sample = 16 * q + s4 + 4 * g;
+                oa[s4] = *reinterpret_cast<const float*>(slot + fb[0] + sample * fs[0]);
+                ob[s4] = *reinterpret_cast<const float*>(slot + fb[1] + sample * fs[1]);
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[0], ob[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[1], ob[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[2], ob[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[3], ob[3], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                        // row 4 g + r, column lane & 15
+            const float sum = acc0[r] + acc1[r];
+            float* q = out + k * 256 + (4 * g + r) * 16 + (lane & 15);
+            if (SC1) st_sc1(q, sum); else *q = sum;
+        }
     }
 }
 
-// ---- reducer: 32 outputs x 32 row groups per workgroup, float64, fixed order ------------------------------------------------
-__device__ __forceinline__ void lin_reduce(const LinArgs& a, char* smem, int rb, int no) {
-    double* sums = reinterpret_cast<double*>(smem);       // [32][32]
+// ---- reducer: 32 outputs x 16 row groups per workgroup, float64, fixed order ------------------------------------------------
+template <bool SC1>
+__device__ __forceinline__ void lin_reduce(const float* partial_in, double* M_out, int ntiles, char* smem, int rb, int no) {
+    double* sums = reinterpret_cast<double*>(smem);       // [16][32]
     const int t = threadIdx.x, o = rb * 32 + (t & 31), rg = t >> 5;
-    const int rpg = (a.ntiles + 31) / 32, r_lo = rg * rpg, r_hi = min(a.ntiles, r_lo + rpg);
+    const int rpg = (ntiles + 15) / 16, r_lo = rg * rpg, r_hi = min(ntiles, r_lo + rpg);
     double s = 0.0;
     if (o < no)
-        for (int r0 = r_lo; r0 < r_hi; r0 += 8) {
-            float tv[8];
+        for (int r0 = r_lo; r0 < r_hi; r0 += 16) {
+            float tv[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) tv[u] = a.partial_in[(long long)min(r0 + u, r_hi - 1) * no + o];     // unconditional, clamped
+            for (int u = 0; u < 16; ++u) {                 // unconditional, clamped
+                const float* q = partial_in + (long long)min(r0 + u, r_hi - 1) * no + o;
+                tv[u] = SC1 ? ld_sc1(q) : *q;
+            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += r0 + u < r_hi ? (double)tv[u] : 0.0;
+            for (int u = 0; u < 16; ++u) s += r0 + u < r_hi ? (double)tv[u] : 0.0;
         }
     sums[rg * 32 + (t & 31)] = s;
     __syncthreads();
     if (t < 32 && o < no) {
         double tot = 0.0;
 #pragma unroll
-        for (int k = 0; k < 32; ++k) tot += sums[k * 32 + t];
-        a.M_out[o] = tot;
+        for (int k = 0; k < 16; ++k) tot += sums[k * 32 + t];
+        if (SC1) st_sc1(M_out + o, tot); else M_out[o] = tot;
     }
 }
 
@@ -219,220 +249,377 @@ __device__ __forceinline__ void lin_reduce(const LinArgs& a, char* smem, int rb,
 //     sum_b |r_b|^2 = tr(R M R^T) = sum_{l,d} Wd[l][d] dwd[l][d] + sum_d (-P1[d][x_d] + sigma P1[d][z2_d] + bd_d P1[d][one])
 //     sum_b |mu_b|^2 = tr(E M E^T) = sum_l (sum_dd We[dd][l] Q[l][x_dd] + be_l Q[l][one])
 // DT, LT > 0: the dimensions at compile time (the metric's 12 / 20: fully unrolled inner products); 0: run-time.
+// The parameters and Adam moments of this thread's outputs (idx = t + 512 k) live in its registers; the float64 copies the
+// products read live in LDS and are refreshed by the owning thread after each update, so a persistent updater touches global
+// memory per step only for M, the loss and (at the end) the results.
+constexpr int LKOUT = 4;                              // P + 4 <= 2 048 at L + 2 D + 1 <= 64
 template <int NB, int DT, int LT>
-__device__ __forceinline__ void lin_update(const LinArgs& a, char* smem) {
-    constexpr int NFP = 16 * NB, NBLK = NB * (NB + 1) / 2;
-    const int t = threadIdx.x, D = DT ? DT : a.D, L = LT ? LT : a.L, P = a.P;
-    const int fone = L + 2 * D;
-    const int off_be = D * L, off_wd = off_be + L, off_bd = off_wd + L * D, off_epsp = off_bd + D;
-    // LDS carve, all float64
-    double* Mf = reinterpret_cast<double*>(smem);         // [NFP][NFP] symmetric
-    double* SM = Mf + NFP * NFP;                           // [L][NFP]
-    double* P1 = SM + L * NFP;                             // [D][NFP]
-    double* G = P1 + D * NFP;                              // [L][NFP]
-    double* Wed = G + L * NFP;                             // [D][L]   encoder kernel (flax [in, out])
-    double* Wdd = Wed + D * L;                             // [L][D]   decoder kernel
-    double* bed = Wdd + L * D;                             // [L]
-    double* bdd = bed + L;                                 // [D]
-    double* sd = bdd + D;                                  // [L] e^{lv/2}
-    double* elv = sd + L;                                  // [L] e^{lv}
-    double* dwd = elv + L;                                 // [L][D]
-    double* red = dwd + L * D;                             // [4 sums][16 waves]
-    LIN_STAMP(0);
-    const int tstep = a.step_dev[0] + 1;
-    // this thread's outputs idx = t + 256 k: parameter and Adam state now, used at the very end (their latency is free here)
-    constexpr int KOUT = 2;                               // P + 4 <= 2 048 at L + 2 D + 1 <= 64
-    float p_old[KOUT], m_old[KOUT], v_old[KOUT];
-#pragma unroll
-    for (int k = 0; k < KOUT; ++k) {
-        const int idx = min(t + LNT * k, P - 1);
-        p_old[k] = a.params[idx]; m_old[k] = a.m[idx]; v_old[k] = a.v[idx];
-    }
-    for (int i = t; i < off_epsp + L; i += LNT) {           // parameters as float64, each in the array the products read
-        const double pv = (double)a.params[i];
-        if (i < off_be) Wed[i] = pv;
-        else if (i < off_wd) bed[i - off_be] = pv;
-        else if (i < off_bd) Wdd[i - off_wd] = pv;
-        else if (i < off_epsp) bdd[i - off_bd] = pv;
-        else { sd[i - off_epsp] = exp(0.5 * pv); elv[i - off_epsp] = exp(pv); }
-    }
-    const double eps = a.off_eps >= 0 ? (double)a.params[a.off_eps] * (double)a.eps_cli : (double)a.eps_cli;
-    for (int e = t; e < NBLK * 256; e += LNT) {
-        const int k = e >> 8, i = (e >> 4) & 15, j = e & 15;
-        int b1 = 0, rem = k;
-        while (rem >= NB - b1) { rem -= NB - b1; ++b1; }
-        const int b2 = b1 + rem;
-        const double v = a.M_in[e];
-        Mf[(16 * b1 + i) * NFP + 16 * b2 + j] = v;
-        Mf[(16 * b2 + j) * NFP + 16 * b1 + i] = v;         // (diagonal blocks are bitwise symmetric: same products, same order)
-    }
-    const double sigma = exp(0.5 * eps), inv_var = exp(-eps);
-    __syncthreads();
-    LIN_STAMP(1);
-    for (int e = t; e < L * NFP; e += LNT) {              // SM = S M
-        const int l = e / NFP, f = e % NFP;
-        double s = sd[l] * Mf[l * NFP + f] + bed[l] * Mf[fone * NFP + f];
-#pragma unroll
-        for (int dd = 0; dd < (DT ? DT : 32); ++dd) if (DT || dd < D) s += Wed[dd * L + l] * Mf[(L + dd) * NFP + f];
-        SM[e] = s;
-    }
-    __syncthreads();
-    LIN_STAMP(2);
-    for (int e = t; e < D * NFP; e += LNT) {              // P1 = R M
-        const int d = e / NFP, f = e % NFP;
-        double s = sigma * Mf[(L + D + d) * NFP + f] - Mf[(L + d) * NFP + f] + bdd[d] * Mf[fone * NFP + f];
-#pragma unroll
-        for (int l = 0; l < (LT ? LT : 32); ++l) if (LT || l < L) s += Wdd[l * D + d] * SM[l * NFP + f];
-        P1[e] = s;
-    }
-    __syncthreads();
-    LIN_STAMP(3);
-    for (int e = t; e < L * NFP; e += LNT) {              // G = Wd P1
-        const int l = e / NFP, f = e % NFP;
-        double s = 0.0;
-#pragma unroll
-        for (int d = 0; d < (DT ? DT : 32); ++d) if (DT || d < D) s += Wdd[l * D + d] * P1[d * NFP + f];
-        G[e] = s;
-    }
-    for (int e = t; e < L * D; e += LNT) {                // dwd[l][d] = S[l,:] . P1[d,:]
-        const int l = e / D, d = e % D;
-        double s = sd[l] * P1[d * NFP + l] + bed[l] * P1[d * NFP + fone];
-#pragma unroll
-        for (int dd = 0; dd < (DT ? DT : 32); ++dd) if (DT || dd < D) s += Wed[dd * L + l] * P1[d * NFP + L + dd];
-        dwd[e] = s;
-    }
-    __syncthreads();
-    LIN_STAMP(4);
-    // the four scalar sums: each thread a strided share, lanes by xor-shuffle, the four waves in order (all fixed order)
-    double p_ssq = 0.0, p_musq = 0.0, p_z2r = 0.0, p_klc = 0.0;
-    for (int e = t; e < L * D; e += LNT) p_ssq += Wdd[e] * dwd[e];
-    if (t < D) {
-        p_ssq += -P1[t * NFP + L + t] + sigma * P1[t * NFP + L + D + t] + bdd[t] * P1[t * NFP + fone];
-        p_z2r = P1[t * NFP + L + D + t];
-    }
-    for (int e = t; e < L * (D + 1); e += LNT) {
-        const int l = e / (D + 1), dd = e % (D + 1);
-        const int f = dd < D ? L + dd : fone;
-        const double q = SM[l * NFP + f] - sd[l] * Mf[l * NFP + f];            // Q = E M
-        p_musq += (dd < D ? Wed[dd * L + l] : bed[l]) * q;
-    }
-    if (t < L) p_klc = 1.0 + 2.0 * log(sd[t]) - elv[t];                        // 1 + lv - e^{lv}
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        p_ssq += __shfl_xor(p_ssq, o, 64); p_musq += __shfl_xor(p_musq, o, 64);
-        p_z2r += __shfl_xor(p_z2r, o, 64); p_klc += __shfl_xor(p_klc, o, 64);
-    }
-    if ((t & 63) == 0) { red[t >> 6] = p_ssq; red[LNW + (t >> 6)] = p_musq; red[2 * LNW + (t >> 6)] = p_z2r; red[3 * LNW + (t >> 6)] = p_klc; }
-    __syncthreads();
-    LIN_STAMP(5);
-    double ssq = 0.0, musq = 0.0, z2r = 0.0, klc = 0.0;
-#pragma unroll
-    for (int w = 0; w < LNW; ++w) { ssq += red[w]; musq += red[LNW + w]; z2r += red[2 * LNW + w]; klc += red[3 * LNW + w]; }
-    LIN_STAMP(6);
-    const double inv_bt = (double)a.inv_bt, rows = (double)a.rows, c0 = inv_var * inv_bt;
-    float bc1, bc2;
-    bc1 = -expm1f((float)tstep * -0.10536051565782628f);
-    bc2 = -expm1f((float)tstep * -0.0010005003335835335f);
-#pragma unroll
-    for (int k = 0; k < KOUT; ++k) {
-        const int idx = t + LNT * k;
-        if (idx >= P + kExtra) continue;
-        double gd = 0.0;
-        if (idx < off_be) { const int d = idx / L, l = idx % L; gd = c0 * G[l * NFP + L + d] + (SM[l * NFP + L + d] - sd[l] * Mf[l * NFP + L + d]) * inv_bt; }
-        else if (idx < off_wd) { const int l = idx - off_be; gd = c0 * G[l * NFP + fone] + (SM[l * NFP + fone] - sd[l] * Mf[l * NFP + fone]) * inv_bt; }
-        else if (idx < off_bd) gd = c0 * dwd[idx - off_wd];
-        else if (idx < off_epsp) gd = c0 * P1[(idx - off_bd) * NFP + fone];
-        else if (idx < off_epsp + L) {
-            const int l = idx - off_epsp;
-            gd = 0.5 * sd[l] * c0 * G[l * NFP + l] - 0.5 * (1.0 - elv[l]) * (double)a.rows_over_bt;
-        } else if (idx == a.off_eps) {
-            gd = (double)a.eps_cli * (-0.5 * ssq * inv_var + 0.5 * rows * D + 0.5 * sigma * z2r * inv_var) * inv_bt;
-        } else if (idx >= P && idx < P + 3) {
-            const double dkl = (0.5 * musq - 0.5 * rows * klc) * inv_bt;
-            const double mse = (0.5 * ssq * inv_var + 0.5 * rows * D * ((double)kLog2Pi + eps)) * inv_bt;
-            gd = idx == P ? dkl + mse : (idx == P + 1 ? dkl : mse);
-        }
-        const float gf = (float)gd;
-        a.grads[idx] = gf;
-        if (idx == P && a.loss_hist) a.loss_hist[(long long)(tstep - 1) % a.loss_hist_cap] = gf;
-        if (idx < P) {
-            float p = p_old[k], mm = m_old[k], vv = v_old[k];
-            adam_apply_f(p, gf, mm, vv, a.lr, bc1, bc2);
-            a.params[idx] = p; a.m[idx] = mm; a.v[idx] = vv;
-        }
-    }
-    if (t == 0) a.step_dev[0] = tstep;
-    LIN_STAMP(7);
-}
+struct LinUpd {
+    static constexpr int NFP = 16 * NB, NBLK = NB * (NB + 1) / 2;
+    int D, L, P, fone, off_be, off_wd, off_bd, off_epsp, off_eps;
+    double *Mf, *SM, *P1, *G, *Wed, *Wdd, *bed, *bdd, *sd, *elv, *dwd, *red, *epsv;
+    float p[LKOUT], m[LKOUT], v[LKOUT];
 
+    __device__ __forceinline__ void carve(const LinArgs& a, char* smem) {
+        D = DT ? DT : a.D; L = LT ? LT : a.L; P = a.P; fone = L + 2 * D; off_eps = a.off_eps;
+        off_be = D * L; off_wd = off_be + L; off_bd = off_wd + L * D; off_epsp = off_bd + D;
+        Mf = reinterpret_cast<double*>(smem);             // [NFP][NFP] symmetric
+        SM = Mf + NFP * NFP; P1 = SM + L * NFP; G = P1 + D * NFP;
+        Wed = G + L * NFP; Wdd = Wed + D * L; bed = Wdd + L * D; bdd = bed + L; sd = bdd + D; elv = sd + L;
+        dwd = elv + L; red = dwd + L * D; epsv = red + 4 * LNW;
+    }
+    static __host__ size_t lds_bytes(int D, int L) {
+        return sizeof(double) * ((size_t)NFP * NFP + (size_t)(D + 2 * L) * NFP + 3 * (size_t)D * L + 4 * L + D + 4 * LNW + 2);
+    }
+    __device__ __forceinline__ void load_state(const LinArgs& a) {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < LKOUT; ++k) {
+            const int idx = min(t + LNT * k, P - 1);
+            p[k] = a.params[idx]; m[k] = a.m[idx]; v[k] = a.v[idx];
+        }
+    }
+    // float64 copies of this thread's own parameters into the arrays the products read
+    __device__ __forceinline__ void publish_params() {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < LKOUT; ++k) {
+            const int i = t + LNT * k;
+            const double pv = (double)p[k];
+            if (i < off_be) Wed[i] = pv;
+            else if (i < off_wd) bed[i - off_be] = pv;
+            else if (i < off_bd) Wdd[i - off_wd] = pv;
+            else if (i < off_epsp) bdd[i - off_bd] = pv;
+            else if (i < off_epsp + L) { sd[i - off_epsp] = exp(0.5 * pv); elv[i - off_epsp] = exp(pv); }
+            else if (i == off_eps) epsv[0] = pv;
+        }
+    }
+    template <bool SC1>
+    __device__ __forceinline__ void expand_M(const double* M_in) {
+        for (int e = threadIdx.x; e < NBLK * 256; e += LNT) {
+            const int k = e >> 8, i = (e >> 4) & 15, j = e & 15;
+            int b1 = 0, rem = k;
+            while (rem >= NB - b1) { rem -= NB - b1; ++b1; }
+            const int b2 = b1 + rem;
+            const double val = SC1 ? ld_sc1(M_in + e) : M_in[e];
+            Mf[(16 * b1 + i) * NFP + 16 * b2 + j] = val;
+            Mf[(16 * b2 + j) * NFP + 16 * b1 + i] = val;   // (diagonal blocks are bitwise symmetric: same products, same order)
+        }
+    }
+    // one step: Mf and the parameter copies are in LDS (a barrier behind them); returns with this thread's p / m / v updated,
+    // its gradients in gout[], and nothing in LDS that the next publish_params / expand_M may not overwrite after a barrier
+    __device__ __forceinline__ void step(const LinArgs& a, int tstep, float (&gout)[LKOUT]) {
+        const int t = threadIdx.x;
+        const double eps = off_eps >= 0 ? epsv[0] * (double)a.eps_cli : (double)a.eps_cli;
+        const double sigma = exp(0.5 * eps), inv_var = exp(-eps);
+        LIN_STAMP(1);
+        for (int e = t; e < L * NFP; e += LNT) {              // SM = S M
+            const int l = e / NFP, f = e % NFP;
+            double s = sd[l] * Mf[l * NFP + f] + bed[l] * Mf[fone * NFP + f];
+#pragma unroll
+            for (int dd = 0; dd < (DT ? DT : 32); ++dd) if (DT || dd < D) s += Wed[dd * L + l] * Mf[(L + dd) * NFP + f];
+            SM[e] = s;
+        }
+        __syncthreads();
+        LIN_STAMP(2);
+        for (int e = t; e < D * NFP; e += LNT) {              // P1 = R M
+            const int d = e / NFP, f = e % NFP;
+            double s = sigma * Mf[(L + D + d) * NFP + f] - Mf[(L + d) * NFP + f] + bdd[d] * Mf[fone * NFP + f];
+#pragma unroll
+            for (int l = 0; l < (LT ? LT : 32); ++l) if (LT || l < L) s += Wdd[l * D + d] * SM[l * NFP + f];
+            P1[e] = s;
+        }
+        __syncthreads();
+        LIN_STAMP(3);
+        for (int e = t; e < L * NFP; e += LNT) {              // G = Wd P1
+            const int l = e / NFP, f = e % NFP;
+            double s = 0.0;
+#pragma unroll
+            for (int d = 0; d < (DT ? DT : 32); ++d) if (DT || d < D) s += Wdd[l * D + d] * P1[d * NFP + f];
+            G[e] = s;
+        }
+        for (int e = t; e < L * D; e += LNT) {                // dwd[l][d] = S[l,:] . P1[d,:]
+            const int l = e / D, d = e % D;
+            double s = sd[l] * P1[d * NFP + l] + bed[l] * P1[d * NFP + fone];
+#pragma unroll
+            for (int dd = 0; dd < (DT ? DT : 32); ++dd) if (DT || dd < D) s += Wed[dd * L + l] * P1[d * NFP + L + dd];
+            dwd[e] = s;
+        }
+        __syncthreads();
+        LIN_STAMP(4);
+        // the four scalar sums: each thread a strided share, lanes by xor-shuffle, the waves in order (all fixed order)
+        double p_ssq = 0.0, p_musq = 0.0, p_z2r = 0.0, p_klc = 0.0;
+        for (int e = t; e < L * D; e += LNT) p_ssq += Wdd[e] * dwd[e];
+        if (t < D) {
+            p_ssq += -P1[t * NFP + L + t] + sigma * P1[t * NFP + L + D + t] + bdd[t] * P1[t * NFP + fone];
+            p_z2r = P1[t * NFP + L + D + t];
+        }
+        for (int e = t; e < L * (D + 1); e += LNT) {
+            const int l = e / (D + 1), dd = e % (D + 1);
+            const int f = dd < D ? L + dd : fone;
+            const double q = SM[l * NFP + f] - sd[l] * Mf[l * NFP + f];            // Q = E M
+            p_musq += (dd < D ? Wed[dd * L + l] : bed[l]) * q;
+        }
+        if (t < L) p_klc = 1.0 + 2.0 * log(sd[t]) - elv[t];                        // 1 + lv - e^{lv}
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            p_ssq += __shfl_xor(p_ssq, o, 64); p_musq += __shfl_xor(p_musq, o, 64);
+            p_z2r += __shfl_xor(p_z2r, o, 64); p_klc += __shfl_xor(p_klc, o, 64);
+        }
+        if ((t & 63) == 0) { red[t >> 6] = p_ssq; red[LNW + (t >> 6)] = p_musq; red[2 * LNW + (t >> 6)] = p_z2r; red[3 * LNW + (t >> 6)] = p_klc; }
+        __syncthreads();
+        LIN_STAMP(5);
+        double ssq = 0.0, musq = 0.0, z2r = 0.0, klc = 0.0;
+#pragma unroll
+        for (int w = 0; w < LNW; ++w) { ssq += red[w]; musq += red[LNW + w]; z2r += red[2 * LNW + w]; klc += red[3 * LNW + w]; }
+        const double inv_bt = (double)a.inv_bt, rows = (double)a.rows, c0 = inv_var * inv_bt;
+        const float bc1 = -expm1f((float)tstep * -0.10536051565782628f), bc2 = -expm1f((float)tstep * -0.0010005003335835335f);
+#pragma unroll
+        for (int k = 0; k < LKOUT; ++k) {
+            const int idx = t + LNT * k;
+            double gd = 0.0;
+            if (idx < off_be) { const int d = idx / L, l = idx % L; gd = c0 * G[l * NFP + L + d] + (SM[l * NFP + L + d] - sd[l] * Mf[l * NFP + L + d]) * inv_bt; }
+            else if (idx < off_wd) { const int l = idx - off_be; gd = c0 * G[l * NFP + fone] + (SM[l * NFP + fone] - sd[l] * Mf[l * NFP + fone]) * inv_bt; }
+            else if (idx < off_bd) gd = c0 * dwd[idx - off_wd];
+            else if (idx < off_epsp) gd = c0 * P1[(idx - off_bd) * NFP + fone];
+            else if (idx < off_epsp + L) {
+                const int l = idx - off_epsp;
+                gd = 0.5 * sd[l] * c0 * G[l * NFP + l] - 0.5 * (1.0 - elv[l]) * (double)a.rows_over_bt;
+            } else if (idx == off_eps) {
+                gd = (double)a.eps_cli * (-0.5 * ssq * inv_var + 0.5 * rows * D + 0.5 * sigma * z2r * inv_var) * inv_bt;
+            } else if (idx >= P && idx < P + 3) {
+                const double dkl = (0.5 * musq - 0.5 * rows * klc) * inv_bt;
+                const double mse = (0.5 * ssq * inv_var + 0.5 * rows * D * ((double)kLog2Pi + eps)) * inv_bt;
+                gd = idx == P ? dkl + mse : (idx == P + 1 ? dkl : mse);
+            }
+            const float gf = (float)gd;
+            gout[k] = gf;
+            if (idx == P && a.loss_hist) a.loss_hist[(long long)(tstep - 1) % a.loss_hist_cap] = gf;
+            if (idx < P) adam_apply_f(p[k], gf, m[k], v[k], a.lr, bc1, bc2);
+        }
+        LIN_STAMP(6);
+    }
+    __device__ __forceinline__ void store_state(const LinArgs& a, const float (&gout)[LKOUT], int tstep) {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < LKOUT; ++k) {
+            const int idx = t + LNT * k;
+            if (idx < P + kExtra) a.grads[idx] = gout[k];
+            if (idx < P) { a.params[idx] = p[k]; a.m[idx] = m[k]; a.v[idx] = v[k]; }
+        }
+        if (t == 0) a.step_dev[0] = tstep;
+    }
+};
+
+// ---- launch-per-step form ---------------------------------------------------------------------------------------------------------
 template <int NB, int DT, int LT>
 __global__ __launch_bounds__(LNT) void lin_step_kernel(const LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lin_smem[];
-    const int b = blockIdx.x;
-    if (b < a.has_update) lin_update<NB, DT, LT>(a, lin_smem);
-    else if (b < a.has_update + a.n_reduce) lin_reduce(a, lin_smem, b - a.has_update, NB * (NB + 1) / 2 * 256);
-    else lin_stream<NB>(a, lin_smem, b - a.has_update - a.n_reduce);
+    const int b = blockIdx.x, t = threadIdx.x;
+    constexpr int NO = NB * (NB + 1) / 2 * 256;
+    if (b < a.has_update) {
+        LinUpd<NB, DT, LT> u;
+        u.carve(a, lin_smem);
+        LIN_STAMP(0);
+        const int tstep = a.step_dev[0] + 1;
+        u.load_state(a);
+        u.publish_params();
+        u.template expand_M<false>(a.M_in);
+        __syncthreads();
+        float g[LKOUT];
+        u.step(a, tstep, g);
+        u.store_state(a, g, tstep);
+        LIN_STAMP(7);
+    } else if (b < a.has_update + a.n_reduce) {
+        lin_reduce<false>(a.partial_in, a.M_out, a.ntiles, lin_smem, b - a.has_update, NO);
+    } else {
+        const int tile = b - a.has_update - a.n_reduce;
+        const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+        const LinSlot sl(a.D, a.L);
+        lin_issue_tile(a, sl, a.x, a.z1, a.z2, tile, lin_smem, t, wave);
+        lin_wait_vmcnt<0>();
+        __syncthreads();
+        lin_fix_tile(a, sl, a.x, a.z1, a.z2, tile, lin_smem, t);
+        lin_multiply_tile<NB, false>(a, sl, lin_smem, a.partial_out + (long long)tile * NO, t, wave);
+    }
+}
+
+// ---- persistent form: up to kLinMaxPersist steps in one launch ----------------------------------------------------------------
+template <int NB, int DT, int LT>
+__global__ __launch_bounds__(LNT, 4) void lin_persist_kernel(const LinArgs a) {       // 4 waves per SIMD = two workgroups per CU
+    extern __shared__ __attribute__((aligned(16))) char lin_smem[];
+    const int b = blockIdx.x, t = threadIdx.x, N = a.n_steps;
+    constexpr int NO = NB * (NB + 1) / 2 * 256;
+    const int per_set = a.n_reduce / kLinReduceSets;          // reducer workgroups per set = NO / 32
+    if (b < a.has_update) {
+        // ---- the updater: one workgroup, parameters and Adam state in registers / LDS across all N steps -------------------
+        LinUpd<NB, DT, LT> u;
+        u.carve(a, lin_smem);
+        int tstep = a.step_dev[0];
+        u.load_state(a);
+        float g[LKOUT];
+#pragma unroll
+        for (int k = 0; k < LKOUT; ++k) g[k] = 0.f;
+        for (int n = 0; n < N; ++n) {
+            LIN_STAMP(0);
+            u.publish_params();
+            lin_wait_count(a.cnt_reduce + n, (unsigned)per_set, a.status);     // (also the barrier behind publish_params)
+            u.template expand_M<true>(a.M_base + (long long)n * NO);
+            __syncthreads();
+            ++tstep;
+            u.step(a, tstep, g);
+            __syncthreads();                                   // everybody is done reading the LDS copies before they are refreshed
+            LIN_STAMP(7);
+        }
+        u.store_state(a, g, tstep);
+    } else if (b < a.has_update + a.n_reduce) {
+        // ---- reducers: set (rb / per_set) takes batches set, set + 2, ... ------------------------------------------------------
+        const int rb = b - a.has_update, set = rb / per_set, ro = rb % per_set;
+        for (int n = set; n < N; n += kLinReduceSets) {
+            lin_wait_count(a.cnt_stream + n, (unsigned)a.ntiles, a.status);
+            lin_reduce<true>(a.partial_base + (long long)n * a.ntiles * NO, a.M_base + (long long)n * NO, a.ntiles, lin_smem, ro, NO);
+            lin_wait_vmcnt<0>();                               // every storing wave drains its write-through stores ...
+            __syncthreads();                                   // ... before the one lane that signals for the workgroup
+            if (t == 0) __hip_atomic_fetch_add(a.cnt_reduce + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        // ---- streamers: tile `tile` of every batch; the loads of batch n + 1 are issued the moment batch n's products are done --
+        const int tile = b - a.has_update - a.n_reduce;
+        const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+        const LinSlot sl(a.D, a.L);
+        lin_issue_tile(a, sl, a.xs[0], a.z1s[0], a.z2s[0], tile, lin_smem, t, wave);
+        for (int n = 0; n < N; ++n) {
+            lin_wait_vmcnt<0>();                               // tile n has landed; this wave's write-through stores of batch n - 1 are out
+            __syncthreads();
+            if (n >= 1 && t == 0) __hip_atomic_fetch_add(a.cnt_stream + (n - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lin_fix_tile(a, sl, a.xs[n], a.z1s[n], a.z2s[n], tile, lin_smem, t);
+            lin_multiply_tile<NB, true>(a, sl, lin_smem, a.partial_base + ((long long)n * a.ntiles + tile) * NO, t, wave);
+            __syncthreads();                                   // every wave's products are done: the slot is free for the next tile
+            if (n + 1 < N) lin_issue_tile(a, sl, a.xs[n + 1], a.z1s[n + 1], a.z2s[n + 1], tile, lin_smem, t, wave);
+        }
+        lin_wait_vmcnt<0>();
+        __syncthreads();
+        if (t == 0) __hip_atomic_fetch_add(a.cnt_stream + (N - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// device tables of batch pointers (the persistent kernel reads them; 48 pointers per launch keep the kernarg small)
+struct LinTable { const float* x[16]; const float* z1[16]; const float* z2[16]; int n, base; };
+__global__ void lin_table_kernel(const LinTable tb, const float** xs, const float** z1s, const float** z2s) {
+    const int i = threadIdx.x;
+    if (i < tb.n) { xs[tb.base + i] = tb.x[i]; z1s[tb.base + i] = tb.z1[i]; z2s[tb.base + i] = tb.z2[i]; }
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
 // 16-feature blocks of the kernel instantiation that serves this model: 3 (up to 48 features: the metric's 45) or 4
 static int lin_nb(const vaek_ctx* c) { return (c->L + 2 * c->D + 1 + 15) / 16 <= 3 ? 3 : 4; }
+static int lin_no(const vaek_ctx* c) { const int NB = lin_nb(c); return NB * (NB + 1) / 2 * 256; }
 
 bool lin_steps_supported(const vaek_ctx* c) {
     return c->cfg.n_enc_hidden == 0 && c->cfg.n_dec_hidden == 0 && !c->cfg.sigmoid_decoder && c->cfg.dtype == VAEK_F32 &&
            c->cfg.world == 1 && c->L + 2 * c->D + 1 <= 64 && (long long)c->B * std::min(c->D, c->L) >= 8;
 }
-
-static size_t lin_lds_bytes(const vaek_ctx* c) {
-    const int NB = lin_nb(c), NFP = 16 * NB, NBLK = NB * (NB + 1) / 2, D = c->D, L = c->L;
-    const size_t stream_in = (size_t)(L * 1024 + 4095) / 4096 * 4096 + 2 * ((size_t)(D * 1024 + 4095) / 4096 * 4096) + 1024 + 16;
-    const size_t stream_red = (size_t)(NBLK <= 6 ? LNW : LNW / 2) * NBLK * 256 * sizeof(float);
-    const size_t upd = sizeof(double) * ((size_t)NFP * NFP + (size_t)(D + 2 * L) * NFP + 3 * (size_t)D * L + 4 * L + D + 4 * LNW);
-    return std::max(std::max(stream_in, stream_red), std::max(upd, (size_t)32 * 32 * sizeof(double)));
+static size_t lin_lds_need(const vaek_ctx* c) {
+    const int NB = lin_nb(c), D = c->D, L = c->L;
+    const LinSlot sl(D, L);
+    const size_t upd = NB == 3 ? LinUpd<3, 0, 0>::lds_bytes(D, L) : LinUpd<4, 0, 0>::lds_bytes(D, L);
+    return std::max((size_t)sl.bytes, std::max(upd, (size_t)16 * 32 * sizeof(double))) + 64;
 }
+// the persistent form needs two workgroups per CU (1 + 96 + 256 resident workgroups at the metric's size): <= 78 KB of LDS each
+static bool lin_persist_supported(const vaek_ctx* c) { return lin_steps_supported(c) && lin_nb(c) == 3 && lin_lds_need(c) <= 78 * 1024; }
 
-size_t lin_steps_workspace_bytes(const vaek_ctx* c) {
-    if (!lin_steps_supported(c)) return 0;
-    const int NB = lin_nb(c), no = NB * (NB + 1) / 2 * 256, ntiles = (c->B + 255) / 256;
-    return 2 * ((size_t)ntiles * no * sizeof(float) + 256) + 2 * ((size_t)no * sizeof(double) + 256);
+struct LinWs { float* partial; double* M; unsigned* cnt; const float** tab; size_t total; };
+static LinWs lin_carve(const vaek_ctx* c, char* base) {
+    const size_t no = lin_no(c), ntiles = (c->B + 255) / 256;
+    const int slots = lin_persist_supported(c) ? kLinMaxPersist : 2;
+    LinWs w{};
+    size_t off = 0;
+    w.cnt = reinterpret_cast<unsigned*>(base + off); off += 4096;                 // cnt_stream[64] | cnt_reduce[64] | status, one memset
+    w.tab = reinterpret_cast<const float**>(base + off); off += 3 * kLinMaxPersist * sizeof(void*) + 256;
+    w.M = reinterpret_cast<double*>(base + off); off += (size_t)slots * no * sizeof(double) + 256;
+    w.partial = reinterpret_cast<float*>(base + off); off += (size_t)slots * ntiles * no * sizeof(float) + 256;
+    w.total = (off + 255) / 256 * 256;
+    return w;
+}
+size_t lin_steps_workspace_bytes(const vaek_ctx* c) { return lin_steps_supported(c) ? lin_carve(c, nullptr).total : 0; }
+
+typedef void (*LinKernel)(const LinArgs);
+static int lin_fill_common(const vaek_ctx* c, LinArgs& a, float* params, float* grads, float* m, float* v, int32_t* step_dev, float lr) {
+    a.B = c->B; a.D = c->D; a.L = c->L; a.ntiles = (c->B + 255) / 256;
+    a.params = params; a.grads = grads; a.m = m; a.v = v; a.step_dev = step_dev; a.lr = lr;
+    a.inv_bt = (float)(1.0 / (double)c->Bt); a.eps_cli = c->cfg.eps_cli; a.rows = (float)c->B;
+    a.rows_over_bt = (float)((double)c->B / (double)c->Bt); a.off_eps = (int)c->off_eps; a.P = (int)c->P;
+    a.loss_hist = c->loss_hist; a.loss_hist_cap = c->loss_hist_cap;
+    return 0;
 }
 
 int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v, int32_t* step_dev, const float* const* xs,
                     const float* const* z1s, const float* const* z2s, int n_steps, float lr, void* ws, hipStream_t st) {
-    const int NB = lin_nb(c), no = NB * (NB + 1) / 2 * 256, ntiles = (c->B + 255) / 256;
-    char* base = static_cast<char*>(ws) + c->ws_lin;
-    const size_t pbytes = ((size_t)ntiles * no * sizeof(float) + 255) / 256 * 256, mbytes = ((size_t)no * sizeof(double) + 255) / 256 * 256;
-    float* partial[2] = {reinterpret_cast<float*>(base), reinterpret_cast<float*>(base + pbytes)};
-    double* Mbuf[2] = {reinterpret_cast<double*>(base + 2 * pbytes), reinterpret_cast<double*>(base + 2 * pbytes + mbytes)};
-    const size_t lds = lin_lds_bytes(c);
+    const int NB = lin_nb(c), no = lin_no(c), ntiles = (c->B + 255) / 256;
+    const LinWs w = lin_carve(c, static_cast<char*>(ws) + c->ws_lin);
     // the metric's shape with its dimensions at compile time; every other linear model on the run-time instantiations
     const int which = (c->D == 12 && c->L == 20) ? 0 : (NB <= 3 ? 1 : 2);
-    void (*fn)(const LinArgs) = which == 0 ? lin_step_kernel<3, 12, 20> : which == 1 ? lin_step_kernel<3, 0, 0> : lin_step_kernel<4, 0, 0>;
-    static thread_local bool attr_set[3] = {false, false, false};
-    if (!attr_set[which]) {
+    static const char* env = getenv("VAEK_LIN_PERSIST");              // diagnostic: 0 forces the launch-per-step form
+    const bool persistent = lin_persist_supported(c) && !(env && atoi(env) == 0);
+    const size_t lds = lin_lds_need(c);
+    const LinKernel fn = persistent ? (which == 0 ? lin_persist_kernel<3, 12, 20> : lin_persist_kernel<3, 0, 0>)
+                                    : (which == 0 ? lin_step_kernel<3, 12, 20> : which == 1 ? lin_step_kernel<3, 0, 0> : lin_step_kernel<4, 0, 0>);
+    static thread_local bool attr_set[2][3] = {};
+    if (!attr_set[persistent ? 1 : 0][which]) {
         VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[which] = true;
+        attr_set[persistent ? 1 : 0][which] = true;
+    }
+    if (persistent) {
+        for (int s0 = 0; s0 < n_steps; s0 += kLinMaxPersist) {
+            const int n = std::min(kLinMaxPersist, n_steps - s0);
+            VAEK_HIP_CHECK(hipMemsetAsync(w.cnt, 0, 4096, st));
+            const float** txs = w.tab; const float** tz1 = w.tab + kLinMaxPersist; const float** tz2 = w.tab + 2 * kLinMaxPersist;
+            for (int b0 = 0; b0 < n; b0 += 16) {
+                LinTable tb{};
+                tb.n = std::min(16, n - b0); tb.base = b0;
+                for (int i = 0; i < tb.n; ++i) { tb.x[i] = xs[s0 + b0 + i]; tb.z1[i] = z1s[s0 + b0 + i]; tb.z2[i] = z2s[s0 + b0 + i]; }
+                hipLaunchKernelGGL(lin_table_kernel, dim3(1), dim3(64), 0, st, tb, txs, tz1, tz2);
+            }
+            LinArgs a{};
+            lin_fill_common(c, a, params, grads, m, v, step_dev, lr);
+            a.persistent = 1; a.n_steps = n;
+            a.has_update = 1; a.n_reduce = kLinReduceSets * (no / 32); a.n_stream = ntiles;
+            a.xs = txs; a.z1s = tz1; a.z2s = tz2;
+            a.partial_base = w.partial; a.M_base = w.M;
+            a.cnt_stream = w.cnt; a.cnt_reduce = w.cnt + 256; a.status = w.cnt + 512;
+            ProfScope ps("lin_moments_persistent", st);
+            launch_k(ps, fn, dim3((unsigned)(a.has_update + a.n_reduce + a.n_stream)), dim3(LNT), lds, st, a);
+        }
+        VAEK_HIP_CHECK(hipGetLastError());
+        return VAEK_OK;
     }
     static const int roles = getenv("VAEK_LIN_ROLES") ? atoi(getenv("VAEK_LIN_ROLES")) : 7;   // diagnostic: 1 stream, 2 reduce, 4 update
+    const size_t pstride = (size_t)ntiles * no;
     for (int n = 0; n < n_steps + 2; ++n) {       // launch n: stream batch n, reduce batch n - 1, update batch n - 2
         LinArgs a{};
+        lin_fill_common(c, a, params, grads, m, v, step_dev, lr);
         a.has_update = (n >= 2 && (roles & 4)) ? 1 : 0;
-        a.n_reduce = (n >= 1 && n <= n_steps && (roles & 2)) ? (no + 31) / 32 : 0;
+        a.n_reduce = (n >= 1 && n <= n_steps && (roles & 2)) ? no / 32 : 0;
         a.n_stream = (n < n_steps && (roles & 1)) ? ntiles : 0;
         if (a.has_update + a.n_reduce + a.n_stream == 0) continue;
-        a.B = c->B; a.D = c->D; a.L = c->L; a.ntiles = ntiles;
-        if (a.n_stream) { a.x = xs[n]; a.z1 = z1s[n]; a.z2 = z2s[n]; a.partial_out = partial[n & 1]; }
-        if (a.n_reduce) { a.partial_in = partial[(n - 1) & 1]; a.M_out = Mbuf[(n - 1) & 1]; }
-        a.M_in = Mbuf[n & 1];                      // (n - 2) & 1
-        a.params = params; a.grads = grads; a.m = m; a.v = v; a.step_dev = step_dev; a.lr = lr;
-        a.inv_bt = (float)(1.0 / (double)c->Bt); a.eps_cli = c->cfg.eps_cli; a.rows = (float)c->B;
-        a.rows_over_bt = (float)((double)c->B / (double)c->Bt); a.off_eps = (int)c->off_eps; a.P = (int)c->P;
-        a.loss_hist = c->loss_hist; a.loss_hist_cap = c->loss_hist_cap;
-        const unsigned grid = (unsigned)(a.has_update + a.n_reduce + a.n_stream);
+        if (a.n_stream) { a.x = xs[n]; a.z1 = z1s[n]; a.z2 = z2s[n]; a.partial_out = w.partial + (n & 1) * pstride; }
+        if (a.n_reduce) { a.partial_in = w.partial + ((n - 1) & 1) * pstride; a.M_out = w.M + ((n - 1) & 1) * no; }
+        a.M_in = w.M + (n & 1) * no;               // (n - 2) & 1
         ProfScope ps(a.n_stream ? "lin_moments_step" : "lin_moments_drain", st);
-        launch_k(ps, fn, dim3(grid), dim3(LNT), lds, st, a);
+        launch_k(ps, fn, dim3((unsigned)(a.has_update + a.n_reduce + a.n_stream)), dim3(LNT), lds, st, a);
     }
     VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+// synchronous: did a bounded wait of the persistent form ever give up (a workgroup that never became resident, a lost store)?
+int lin_steps_status(vaek_ctx* c, void* ws, int* gave_up) {
+    *gave_up = 0;
+    if (!lin_steps_supported(c)) return VAEK_OK;
+    const LinWs w = lin_carve(c, static_cast<char*>(ws) + c->ws_lin);
+    unsigned s = 0;
+    VAEK_HIP_CHECK(hipMemcpy(&s, w.cnt + 512, sizeof(s), hipMemcpyDeviceToHost));
+    *gave_up = s != 0;
     return VAEK_OK;
 }
 

@@ -280,6 +280,7 @@ bool lin_steps_supported(const vaek_ctx* c);
 size_t lin_steps_workspace_bytes(const vaek_ctx* c);
 int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v, int32_t* step_dev, const float* const* xs,
                     const float* const* z1s, const float* const* z2s, int n_steps, float lr, void* ws, hipStream_t st);
+int lin_steps_status(vaek_ctx* c, void* ws, int* gave_up);
 
 // ---- rng.hip ------------------------------------------------------------------------------
 // validates the arguments of vaek_make_batch* and fills `out`

@@ -138,6 +138,12 @@ class Engine:
         _lib.check(self.lib.vaek_train_steps(self.h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(step_dev), xs, z1s, z2s, n,
                                              float(lr), _ptr(self.workspace), _stream()))
 
+    def train_steps_gave_up(self):
+        """Synchronous: True if a bounded wait inside vaek_train_steps' persistent launch ever expired."""
+        f = C.c_int32()
+        _lib.check(self.lib.vaek_train_steps_status(self.h, _ptr(self.workspace), C.byref(f)))
+        return bool(f.value)
+
     def grads_only(self, params, grads, step_dev, x, z1, z2):
         _lib.check(self.lib.vaek_train_step_grads_only(self.h, _ptr(params), _ptr(grads), _ptr(step_dev), _ptr(x),
                                                        _ptr(z1), _ptr(z2), _ptr(self.workspace), _stream()))
