@@ -378,6 +378,8 @@ def main():
         elapsed = float(t.item())
     loss = float(grads[eng.P].item())
     assert math.isfinite(loss), "train step produced a non-finite loss"
+    if use_pipe:
+        assert not eng.train_steps_gave_up(), "a bounded in-launch wait of vaek_train_steps expired: results invalid"
     if exch is not None and exch.in_library:
         assert not exch.timed_out(), "p2p gradient exchange gave up waiting for a peer"
 
@@ -410,8 +412,10 @@ def main():
                 alg_step = alg + 32 * P
                 peak, unit, bound, scale = 8000.0, "GB/s", "hbm", 1e9
                 if eng.fused:
-                    # one kernel reads every algorithmic input byte: price THAT kernel by its own duration
-                    kernel_s, kernel_name = dom_avg_s, dom
+                    # one kernel reads every algorithmic input byte: price THAT kernel by its own duration (a persistent launch
+                    # of vaek_train_steps covers several steps: its duration per step)
+                    steps_per_launch = rsteps / rep[dom]["count"] if dom.startswith("lin_moments") else 1.0
+                    kernel_s, kernel_name = dom_avg_s / steps_per_launch, dom
                 else:
                     # multi-kernel path: the algorithmic bytes are spread over all launches of the step, so the
                     # denominator is their summed duration (one kernel's duration would overstate the rate)
@@ -429,6 +433,7 @@ def main():
             roofline = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
                         "traffic": traffic, "kernel": kernel_name, "kernel_avg_us": kernel_s * 1e6,
                         "dominant_kernel": dom, "dominant_kernel_avg_us": dom_avg_s * 1e6,
+                        "steps_per_dominant_launch": (rsteps / rep[dom]["count"] if dom.startswith("lin_moments") else 1.0),
                         "launches_per_step": sum(r["count"] for r in rep.values()) / rsteps,
                         "algorithmic_per_launch": alg,
                         # the same algorithmic work priced against the whole step's wall time (launch gaps, finalize, Adam

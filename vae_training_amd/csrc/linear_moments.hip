@@ -257,7 +257,7 @@ template <int NB, int DT, int LT>
 struct LinUpd {
     static constexpr int NFP = 16 * NB, NBLK = NB * (NB + 1) / 2;
     int D, L, P, fone, off_be, off_wd, off_bd, off_epsp, off_eps;
-    double *Mf, *SM, *P1, *G, *Wed, *Wdd, *bed, *bdd, *sd, *elv, *dwd, *red, *epsv;
+    double *Mf, *SM, *P1, *G, *Wed, *Wdd, *bed, *bdd, *sd, *elv, *lvd, *dwd, *red, *epsv;
     float p[LKOUT], m[LKOUT], v[LKOUT];
 
     __device__ __forceinline__ void carve(const LinArgs& a, char* smem) {
@@ -265,11 +265,11 @@ struct LinUpd {
         off_be = D * L; off_wd = off_be + L; off_bd = off_wd + L * D; off_epsp = off_bd + D;
         Mf = reinterpret_cast<double*>(smem);             // [NFP][NFP] symmetric
         SM = Mf + NFP * NFP; P1 = SM + L * NFP; G = P1 + D * NFP;
-        Wed = G + L * NFP; Wdd = Wed + D * L; bed = Wdd + L * D; bdd = bed + L; sd = bdd + D; elv = sd + L;
-        dwd = elv + L; red = dwd + L * D; epsv = red + 4 * LNW;
+        Wed = G + L * NFP; Wdd = Wed + D * L; bed = Wdd + L * D; bdd = bed + L; sd = bdd + D; elv = sd + L; lvd = elv + L;
+        dwd = lvd + L; red = dwd + L * D; epsv = red + 4 * LNW;
     }
     static __host__ size_t lds_bytes(int D, int L) {
-        return sizeof(double) * ((size_t)NFP * NFP + (size_t)(D + 2 * L) * NFP + 3 * (size_t)D * L + 4 * L + D + 4 * LNW + 2);
+        return sizeof(double) * ((size_t)NFP * NFP + (size_t)(D + 2 * L) * NFP + 3 * (size_t)D * L + 5 * L + D + 4 * LNW + 2);
     }
     __device__ __forceinline__ void load_state(const LinArgs& a) {
         const int t = threadIdx.x;
@@ -290,7 +290,7 @@ struct LinUpd {
             else if (i < off_wd) bed[i - off_be] = pv;
             else if (i < off_bd) Wdd[i - off_wd] = pv;
             else if (i < off_epsp) bdd[i - off_bd] = pv;
-            else if (i < off_epsp + L) { sd[i - off_epsp] = exp(0.5 * pv); elv[i - off_epsp] = exp(pv); }
+            else if (i < off_epsp + L) { const double sl = exp(0.5 * pv); sd[i - off_epsp] = sl; elv[i - off_epsp] = sl * sl; lvd[i - off_epsp] = pv; }
             else if (i == off_eps) epsv[0] = pv;
         }
     }
@@ -311,7 +311,7 @@ struct LinUpd {
     __device__ __forceinline__ void step(const LinArgs& a, int tstep, float (&gout)[LKOUT]) {
         const int t = threadIdx.x;
         const double eps = off_eps >= 0 ? epsv[0] * (double)a.eps_cli : (double)a.eps_cli;
-        const double sigma = exp(0.5 * eps), inv_var = exp(-eps);
+        const double sigma = exp(0.5 * eps), inv_var = 1.0 / (sigma * sigma);       // (one float64 exp on the chain, not two)
         LIN_STAMP(1);
         for (int e = t; e < L * NFP; e += LNT) {              // SM = S M
             const int l = e / NFP, f = e % NFP;
@@ -360,7 +360,7 @@ struct LinUpd {
             const double q = SM[l * NFP + f] - sd[l] * Mf[l * NFP + f];            // Q = E M
             p_musq += (dd < D ? Wed[dd * L + l] : bed[l]) * q;
         }
-        if (t < L) p_klc = 1.0 + 2.0 * log(sd[t]) - elv[t];                        // 1 + lv - e^{lv}
+        if (t < L) p_klc = 1.0 + lvd[t] - elv[t];                                  // 1 + lv - e^{lv}
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             p_ssq += __shfl_xor(p_ssq, o, 64); p_musq += __shfl_xor(p_musq, o, 64);
