@@ -379,7 +379,8 @@ def main():
     loss = float(grads[eng.P].item())
     assert math.isfinite(loss), "train step produced a non-finite loss"
     if use_pipe:
-        assert not eng.train_steps_gave_up(), "a bounded in-launch wait of vaek_train_steps expired: results invalid"
+        assert not eng.train_steps_gave_up(), (f"a bounded in-launch wait of vaek_train_steps expired (status "
+                                               f"{eng.train_steps_status_word:#x}, {elapsed:.3f} s for {args.steps} steps): results invalid")
     if exch is not None and exch.in_library:
         assert not exch.timed_out(), "p2p gradient exchange gave up waiting for a peer"
 
@@ -502,7 +503,7 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w['desc']}", "batch_per_gpu": B_local, "global_batch": B_global,
                        "data_dim": D, "latent_dim": L, "params": eng.P, "path": "fused" if eng.fused else "layer-by-layer",
-                       "step_entry_point": ("vaek_train_steps (N steps, software-pipelined over launches)" if use_pipe else "vaek_train_step"),
+                       "step_entry_point": ("vaek_train_steps (up to 64 steps per persistent launch: streamers | reducers | updater)" if use_pipe else "vaek_train_step"),
                        "parallelism": f"dp{world}", "grad_exchange": (exch.mode if exch else "none"),
                        "launch": (f"hipGraph x{gsteps} steps" if graph is not None else "eager"), "input_batches": nbuf,
                        "final_loss": loss},

@@ -228,8 +228,9 @@ int vaek_supports_train_steps(const vaek_ctx* ctx, int32_t* yes);
 int vaek_train_steps(vaek_ctx* ctx, float* params, float* grads, float* m, float* v, int32_t* step_dev,
                      const float* const* xs, const float* const* z1s, const float* const* z2s, int32_t n_steps, float lr,
                      void* workspace, void* stream);
-/* Synchronous (reads one word back): *gave_up = 1 if a bounded in-launch wait of vaek_train_steps' persistent form ever expired
- * (the results of that call are then invalid). */
+/* Synchronous (reads one word back): *gave_up != 0 if a bounded in-launch wait of vaek_train_steps' persistent form ever expired
+ * (the results of that call are then invalid).  The word says which wait: 0x80000000 | role << 28 (1 the updater, 2 a reducer)
+ * | batch index within the launch << 16 | the arrival count it last saw. */
 int vaek_train_steps_status(vaek_ctx* ctx, void* workspace, int32_t* gave_up);
 /* n standard normals and/or the raw Philox words they came from (block b = counter (b_lo, b_hi, step, tag)). */
 int vaek_rng_fill(vaek_ctx* ctx, float* normals, uint32_t* bits, int64_t n, uint64_t seed, uint32_t step, uint32_t tag,

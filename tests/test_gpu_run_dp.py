@@ -57,3 +57,25 @@ def test_rank0_slow_plot_does_not_break_the_p2p_exchange(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     for rank in (0, 1):
         assert f"RESULT rank={rank} replicas_identical=True timed_out=False steps=30" in r.stdout, r.stdout[-1500:]
+
+
+@pytest.mark.parametrize("comm,port", [("p2p", 29521), ("rccl", 29522)])
+def test_bench_py_two_ranks_rehearsed_on_one_gpu(comm, port):
+    """The driver's multi-GPU bench command line, at two ranks sharing this box's one GPU (--rehearse-one-gpu: both ranks on
+    cuda:0, gloo standing in for RCCL's rendezvous): rank 0 prints exactly one JSON line for n_gpus 2 with the whole-job rate,
+    the loss is finite, and the in-kernel P2P exchange records no time-out (bench.py asserts both before it prints)."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--steps", "20",
+           "--warmup", "5", "--comm", comm, "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 5 and out["scaling"] == "weak"
+    assert out["unit"] == "samples/s" and out["config"]["parallelism"] == "dp2", out
+    assert out["config"]["global_batch"] == 2 * out["config"]["batch_per_gpu"]
+    assert np.isfinite(out["value"]) and out["value"] > 0 and np.isfinite(out["config"]["final_loss"]), out
+    assert out["config"]["grad_exchange"] == comm, out["config"]
+    assert out["config"]["step_entry_point"] == "vaek_train_step"      # vaek_train_steps is single-GPU for now

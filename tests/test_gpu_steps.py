@@ -136,3 +136,46 @@ print(json.dumps({"p": params.cpu().numpy().view(np.int32).tolist(), "m": m.cpu(
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert outs[0] == outs[1]
+
+
+def test_graph_replay_of_pipelined_steps_equals_the_eager_call():
+    """vaek_train_steps captured into a hipGraph (bench.py's steady-state loop) and replayed: bitwise the parameters, moments and
+    losses of the same call made eagerly -- the zeroing of the arrival counters and every hand-off of the persistent launch must
+    survive capture -- and no bounded wait expires."""
+    cfg, dk, _, lr = build("c1_linear_L20")
+    B, n = 70000, 130                                  # 274 tiles; two full persistent launches and a short one per call
+    p, batches = _problem(cfg, dk, B, 6)
+    dbat = [tuple(dev(a) for a in b) for b in batches]
+    seq = [dbat[i % len(dbat)] for i in range(n)]
+    eng = engine_for(cfg, B)
+
+    def fresh():
+        return (dev(O.flatten(cfg, p)), eng.new_flat(eng.grad_len), eng.new_flat(), eng.new_flat(),
+                torch.zeros(1, dtype=torch.int32, device="cuda"))
+
+    pe, ge, me, ve, se = fresh()
+    ring_e = torch.zeros(2 * n + 8, dtype=torch.float32, device="cuda")
+    eng.set_loss_history(ring_e)
+    eng.train_steps(pe, ge, me, ve, se, seq, lr)
+    eng.train_steps(pe, ge, me, ve, se, seq, lr)
+    torch.cuda.synchronize()
+    assert not eng.train_steps_gave_up(), hex(eng.train_steps_status_word)
+
+    pg, gg, mg, vg, sg = fresh()
+    ring_g = torch.zeros(2 * n + 8, dtype=torch.float32, device="cuda")
+    eng.set_loss_history(ring_g)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            eng.train_steps(pg, gg, mg, vg, sg, seq, lr)
+    torch.cuda.current_stream().wait_stream(side)
+    graph.replay()
+    graph.replay()
+    torch.cuda.synchronize()
+    eng.set_loss_history(None)
+    assert not eng.train_steps_gave_up(), hex(eng.train_steps_status_word)
+    assert int(sg.item()) == int(se.item()) == 2 * n
+    assert torch.equal(pg, pe) and torch.equal(mg, me) and torch.equal(vg, ve) and torch.equal(gg, ge)
+    assert torch.equal(ring_g, ring_e) and float(ring_e[2 * n - 1]) < float(ring_e[0])

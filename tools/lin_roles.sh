@@ -1,0 +1,26 @@
+# Diagnostic: the persistent form of vaek_train_steps with some roles left out (VAEK_LIN_ROLES: 1 streamers only, 3 + reducers,
+# 7 everything), 64 steps of the metric's shape timed with events around the call.  Results are garbage unless ROLES=7.
+cd $GRAFT_REPO_ROOT
+for cfg in ${CFGS:-1:0 3:0 7:0}; do
+VAEK_LIN_ROLES=${cfg%%:*} VAEK_LIN_DIAG=${cfg##*:} python3 - <<'PY'
+import sys, os
+sys.path.insert(0, os.getcwd())
+import torch
+from bench import WORKLOADS, data_dim, init_params_flat, make_batches
+from vae_training_amd.engine import Engine
+w = WORKLOADS["M"]; B = int(os.environ.get("LIN_B", 65536))
+eng = Engine(B, data_dim(w), w["L"], (), (), w["eps"], w["tdv"], False)
+params = init_params_flat(eng, 0); grads = eng.new_flat(eng.grad_len); m = eng.new_flat(); v = eng.new_flat()
+step = torch.zeros(1, dtype=torch.int32, device="cuda")
+batches = make_batches(w, B, eng.device, 48, seed=1)
+out = []
+for it in range(4):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    eng.train_steps(params, grads, m, v, step, [batches[i % len(batches)] for i in range(64)], 1e-3)
+    e1.record()
+    torch.cuda.synchronize()
+    out.append(e0.elapsed_time(e1) * 1e3 / 64)
+print("roles", os.environ["VAEK_LIN_ROLES"], "diag", os.environ["VAEK_LIN_DIAG"], "rwg", os.environ.get("VAEK_LIN_RWG"), "us/step:", " ".join(f"{x:.2f}" for x in out))
+PY
+done

@@ -6,26 +6,51 @@ mkdir -p /tmp/linst && for f in api gemm_f32 gemm_bf16 gemm_bf16s gemm_skinny16 
 done; wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/linst/libvaek.so /tmp/linst/*.o
 cd $GRAFT_REPO_ROOT
-VAEK_LIB_PATH=/tmp/linst/libvaek.so VAEK_LIN_ROLES=${ROLES:-4} python3 - <<'PY'
+# PERSIST=1: the persistent form with all roles (stamps of the LAST step of the launch; 9 = params published, 8 = wait over)
+if [ "${PERSIST:-0}" = "1" ]; then export VAEK_LIN_PERSIST=1; else export VAEK_LIN_PERSIST=0 VAEK_LIN_ROLES=${ROLES:-4}; fi
+VAEK_LIB_PATH=/tmp/linst/libvaek.so python3 - <<'PY'
 import ctypes as C, sys, os
 sys.path.insert(0, os.getcwd())
 import torch
 from bench import WORKLOADS, data_dim, init_params_flat, make_batches
 from vae_training_amd.engine import Engine
 w = WORKLOADS["M"]; B = 65536
+persist = os.environ.get("VAEK_LIN_PERSIST") == "1"
 eng = Engine(B, data_dim(w), w["L"], (), (), w["eps"], w["tdv"], False)
 params = init_params_flat(eng, 0); grads = eng.new_flat(eng.grad_len); m = eng.new_flat(); v = eng.new_flat()
 step = torch.zeros(1, dtype=torch.int32, device="cuda")
-batches = make_batches(w, B, eng.device, 4, seed=1)
-buf = torch.zeros(16, dtype=torch.int64, device="cuda")
+batches = make_batches(w, B, eng.device, 48 if persist else 4, seed=1)
+buf = torch.zeros(256, dtype=torch.int64, device="cuda")
 assert eng.lib.vaek_debug_lin_stamps(C.c_void_p(buf.data_ptr())) == 0
-for _ in range(3):
-    eng.train_steps(params, grads, m, v, step, batches, 1e-3)
-torch.cuda.synchronize()
+for nsteps in ((40, 64, 64) if persist else (4, 4, 4)):
+    buf.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    eng.train_steps(params, grads, m, v, step, [batches[i % len(batches)] for i in range(nsteps)], 1e-3)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"{nsteps} steps: {e0.elapsed_time(e1) * 1e3 / nsteps:.2f} us/step (events around the call)")
 t = buf.cpu().numpy()
-names = ["load params + expand M", "e^{lv/2}", "build R, E", "P1 = R M, Q = E M", "G, dWd, partial sums", "tree reduce", "outputs + Adam"]
-print("updater phases (cycles):")
+if persist:
+    assert not eng.train_steps_gave_up()
+    print(f"   loop entry -> end of last step: {(t[16 + 7] - t[16 + 10]) / 100.0:.1f} us (s_memrealtime, 100 MHz) = {(t[7] - t[10])} s_memtime ticks")
+    print(f"   last step: {(t[16 + 7] - t[16 + 0]) / 100.0:.2f} us")
+    print(f"   waiting for the reducers: total {t[11] / 100.0:.1f} us, first step {t[13] / 100.0:.1f} us, longest {t[12] / 100.0:.1f} us")
+    t0 = t[16 + 10]
+    print(f"   reducer workgroup 5 (32 of the launch's batches): waiting {t[40] / 100.0:.1f} us, reducing {t[41] / 100.0:.1f} us")
+    print(f"   streamer 7 ({t[46]} work items), us per item: issue next {t[42] / 100.0 / t[46]:.2f}, wait for the tile {t[43] / 100.0 / t[46]:.2f}, fix {t[44] / 100.0 / t[46]:.2f}, multiply + barrier {t[45] / 100.0 / t[46]:.2f}")
+    print("   batch: reduced at | updated at  (us after the updater entered its loop; last arrival of each role)")
+    for n in range(0, 64, 3):
+        print(f"   {n:3d}   {(t[128 + n] - t0) / 100.0:8.1f}   {(t[64 + n] - t0) / 100.0:8.1f}")
+    print("updater, last step of the launch (s_memtime ticks):")
+    print(f"   publish params               {t[9] - t[0]:8d}")
+    print(f"   wait for the reducers        {t[8] - t[9]:8d}")
+    print(f"   expand M                     {t[1] - t[8]:8d}")
+else:
+    print("updater phases (ticks):")
+    print(f"   load params + expand M       {t[1] - t[0]:8d}")
+names = ["e^{lv/2}", "SM", "P1", "G, dWd, partial sums", "tree reduce", "outputs + Adam"]
 for i, n in enumerate(names):
-    print(f"   {n:28s} {t[i + 1] - t[i]:8d}")
+    print(f"   {n:28s} {t[i + 2] - t[i + 1]:8d}")
 print("   total", t[7] - t[0])
 PY

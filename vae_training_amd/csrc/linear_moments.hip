@@ -50,6 +50,8 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 constexpr int LNT = 512, LNW = LNT / 64;          // threads / waves per workgroup, every role
 constexpr int kLinMaxPersist = 64;                // steps per persistent launch (each owns a partial / M slot)
 constexpr int kLinReduceSets = 2;                 // persistent form: reducer sets taking alternate batches
+constexpr int kLinReduceWgs = 12;                 // workgroups per set, each summing NO / 32 / 12 slices of 32 outputs (more resident
+                                                  // workgroups measurably slow the streamers: 48 per set cost 2 us per step)
 
 struct LinArgs {
     // roles by blockIdx.x: [0, has_update) the updater, then n_reduce reducers, then n_stream streamers
@@ -60,7 +62,7 @@ struct LinArgs {
     const float* partial_in; double* M_out;                                       // [NBLK * 256]
     const double* M_in;
     // ---- persistent form: n_steps batches, pointer tables in device memory, one slot per batch, arrival counters
-    int persistent, n_steps;
+    int persistent, n_steps, diag;
     const float* const* xs; const float* const* z1s; const float* const* z2s;
     float* partial_base; double* M_base;                                          // slot n at + n * ntiles * NO resp. + n * NO
     unsigned* cnt_stream; unsigned* cnt_reduce; unsigned* status;                 // [n_steps], [n_steps], [1]; zeroed before the launch
@@ -76,18 +78,50 @@ __device__ unsigned long long* g_lin_stamp_buf = nullptr;
     do {                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         unsigned long long _t;                                                                               \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); \
-        if (g_lin_stamp_buf && threadIdx.x == 0) g_lin_stamp_buf[i] = _t;                                    \
+        unsigned long long _r;                                                                               \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t), "=s"(_r)::"memory"); \
+        if (g_lin_stamp_buf && threadIdx.x == 0) { g_lin_stamp_buf[i] = _t; g_lin_stamp_buf[16 + (i)] = _r; } \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
     } while (0)
+#define LIN_NOW(v)                                                                                           \
+    do {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    } while (0)
+#define LIN_NOWQ(v)  /* no vmcnt wait: does not drain the wave's stores */                                   \
+    do {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    } while (0)
+#define LIN_PUT(i, v) do { if (g_lin_stamp_buf && threadIdx.x == 0) g_lin_stamp_buf[i] = (v); } while (0)
+#define LIN_PUTMAX(i, v) do { if (g_lin_stamp_buf && threadIdx.x == 0) atomicMax(&g_lin_stamp_buf[i], (v)); } while (0)
 #else
 #define LIN_STAMP(i) do {} while (0)
+#define LIN_NOW(v) do {} while (0)
+#define LIN_NOWQ(v) do {} while (0)
+#define LIN_PUT(i, v) do {} while (0)
+#define LIN_PUTMAX(i, v) do {} while (0)
 #endif
 
 __device__ __forceinline__ void lin_glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((glb_void_t*)gsrc, (lds_void_t*)lds_wave_base, 16, 0, 0);
 }
 template <int N> __device__ __forceinline__ void lin_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// Workgroup barrier that leaves LDS-DMA loads in flight: __syncthreads() would drain them (its fence waits vmcnt(0) while a
+// global_load_lds is pending: cdna guide, LDS-DMA rules); LDS traffic of this wave is waited for explicitly.
+__device__ __forceinline__ void lin_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// wait until at most n (wave-uniform, <= 12) of this wave's memory operations are outstanding
+__device__ __forceinline__ void lin_wait_vmcnt_upto(int n) {
+    switch (n) {
+        case 1: lin_wait_vmcnt<1>(); break;   case 2: lin_wait_vmcnt<2>(); break;   case 3: lin_wait_vmcnt<3>(); break;
+        case 4: lin_wait_vmcnt<4>(); break;   case 5: lin_wait_vmcnt<5>(); break;   case 6: lin_wait_vmcnt<6>(); break;
+        case 7: lin_wait_vmcnt<7>(); break;   case 8: lin_wait_vmcnt<8>(); break;   case 9: lin_wait_vmcnt<9>(); break;
+        case 10: lin_wait_vmcnt<10>(); break; case 11: lin_wait_vmcnt<11>(); break; case 12: lin_wait_vmcnt<12>(); break;
+        default: lin_wait_vmcnt<0>(); break;
+    }
+}
 
 // block (b1, b2), b1 <= b2, of the upper block triangle -> its index in the packed image
 __device__ __host__ constexpr int lin_blk(int NB, int b1, int b2) { return b1 * NB - b1 * (b1 - 1) / 2 + (b2 - b1); }
@@ -99,15 +133,21 @@ __device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_lo
 __device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // All threads call; thread 0 polls `*cnt >= target` (relaxed, with s_sleep; bounded: ~2 s, then the status word is set and
-// every later wait of the launch returns at once so the grid drains), the workgroup barrier publishes the outcome.
-__device__ __forceinline__ void lin_wait_count(const unsigned* cnt, unsigned target, unsigned* status) {
+// every later wait of the launch returns at once so the grid drains), the workgroup barrier publishes the outcome.  The first
+// wait to expire records who it was: 0x80000000 | role << 28 (1 updater, 2 reducer) | batch << 16 | the count it last saw.
+__device__ __forceinline__ void lin_wait_count(const unsigned* cnt, unsigned target, unsigned* status, unsigned tag) {
     if (threadIdx.x == 0) {
-        unsigned spins = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(8);
-            if ((++spins & 1023u) == 0 && (spins > (1u << 21) || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
+        unsigned spins = 0, seen;
+        while ((seen = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
+            __builtin_amdgcn_s_sleep(16);
+            if ((++spins & 1023u) == 0) {
+                if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if (spins > (1u << 21)) {
+                    unsigned expect = 0;
+                    __hip_atomic_compare_exchange_strong(status, &expect, 0x80000000u | tag | (seen & 0xffffu), __ATOMIC_RELAXED,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
             }
         }
     }
@@ -161,55 +201,67 @@ __device__ __forceinline__ void lin_fix_tile(const LinArgs& a, const LinSlot& sl
         for (int e = valid * L + t; e < 256 * L; e += LNT) reinterpret_cast<float*>(slot)[e] = 0.f;
         for (int e = valid * D + t; e < 256 * D; e += LNT) { reinterpret_cast<float*>(slot + sl.oX)[e] = 0.f; reinterpret_cast<float*>(slot + sl.oZ2)[e] = 0.f; }
     }
-    __syncthreads();
+    lin_barrier();
 }
 
-// M_tile = U^T U.  The BLOCKS, not the samples, are dealt to the waves: wave w owns block w (of the upper block triangle) over
-// all 256 samples -- 64 k-steps of 4 samples, two accumulator chains -- so there is no cross-wave sum, no block images in LDS
-// and no barrier behind the products: the workgroup's whole LDS need is the tile itself (2 workgroups per CU: every role of
-// the persistent launch is resident at once).
+// M_tile = U^T U.  The SAMPLES are dealt to the waves: wave w takes samples 32 w .. 32 w + 31 -- 8 k-steps of 4 samples -- for
+// every block of the upper block triangle, so each operand register read from LDS feeds NB (+1) MFMAs, the matrix pipes of
+// the four SIMDs carry equal loads and the NBLK accumulator chains are independent.  The eight per-wave images are then
+// summed through LDS (in wave order: deterministic) in the tile's own slot, which is dead by then, and leave as one image.
+constexpr int lin_scratch_bytes(int NB) { return LNW * (NB * (NB + 1) / 2) * 1024; }
 template <int NB, bool SC1>
-__device__ __forceinline__ void lin_multiply_tile(const LinArgs& a, const LinSlot& sl, const char* slot, float* out, int t, int wave) {
+__device__ __forceinline__ void lin_multiply_tile(const LinArgs& a, const LinSlot& sl, char* slot, float* out, int t, int wave) {
     constexpr int NBLK = NB * (NB + 1) / 2;
     const int lane = t & 63, g = lane >> 4, D = a.D, L = a.L;
-    for (int k = wave; k < NBLK; k += LNW) {
-        int b1 = 0, rem = k;
-        while (rem >= NB - b1) { rem -= NB - b1; ++b1; }
-        const int b2 = b1 + rem;
-        // where this lane's feature 16 b + (lane & 15) lives (byte offset of sample 0, byte stride per sample)
-        int fb[2], fs[2];
+    // where this lane's feature 16 u + (lane & 15) lives (byte offset of sample 0, byte stride per sample)
+    int fb[NB], fs[NB];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int f = 16 * (u ? b2 : b1) + (lane & 15);
-            if (f < L) { fb[u] = f * 4; fs[u] = L * 4; }
-            else if (f < L + D) { fb[u] = sl.oX + (f - L) * 4; fs[u] = D * 4; }
-            else if (f < L + 2 * D) { fb[u] = sl.oZ2 + (f - L - D) * 4; fs[u] = D * 4; }
-            else if (f == L + 2 * D) { fb[u] = sl.oV; fs[u] = 4; }
-            else { fb[u] = sl.oC; fs[u] = 0; }
-        }
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        // k-step (q, s): lane group g takes sample 16 q + s + 4 g.  The four samples of a step lie 4 rows apart: with 80- and 48-byte
-        // rows that is 16 banks, so the two lane groups ds_read_b32 services together never collide.
-#pragma unroll 4
-        for (int q = 0; q < 16; ++q) {
-            float oa[4], ob[4];
+    for (int u = 0; u < NB; ++u) {
+        const int f = 16 * u + (lane & 15);
+        if (f < L) { fb[u] = f * 4; fs[u] = L * 4; }
+        else if (f < L + D) { fb[u] = sl.oX + (f - L) * 4; fs[u] = D * 4; }
+        else if (f < L + 2 * D) { fb[u] = sl.oZ2 + (f - L - D) * 4; fs[u] = D * 4; }
+        else if (f == L + 2 * D) { fb[u] = sl.oV; fs[u] = 4; }
+        else { fb[u] = sl.oC; fs[u] = 0; }
+    }
+    f32x4 acc[NBLK];
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const int sample = 16 * q + s4 + 4 * g;
-                oa[s4] = *reinterpret_cast<const float*>(slot + fb[0] + sample * fs[0]);
-                ob[s4] = *reinterpret_cast<const float*>(slot + fb[1] + sample * fs[1]);
-            }
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[0], ob[0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[1], ob[1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[2], ob[2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[3], ob[3], acc1, 0, 0, 0);
-        }
+    for (int k = 0; k < NBLK; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // k-step j of this wave: lane group g takes sample 32 w + 16 (j >> 2) + (j & 3) + 4 g.  The four samples of a step lie 4 rows
+    // apart: with 80- and 48-byte rows that is 16 banks, so the lane groups one ds_read_b32 services together never collide.
+    // Operands run one step ahead in a second register set, and the scheduler is told to keep it that way: left alone hipcc
+    // reuses one register set and waits out the full LDS latency before every MFMA.
+    float op[2][NB];
+    auto fetch = [&](int set, int j) {
+        const int sample = 32 * wave + 16 * (j >> 2) + (j & 3) + 4 * g;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {                        // row 4 g + r, column lane & 15
-            const float sum = acc0[r] + acc1[r];
-            float* q = out + k * 256 + (4 * g + r) * 16 + (lane & 15);
-            if (SC1) st_sc1(q, sum); else *q = sum;
-        }
+        for (int u = 0; u < NB; ++u) op[set][u] = *reinterpret_cast<const float*>(slot + fb[u] + sample * fs[u]);
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int cur = j & 1;
+        if (j + 1 < 8) fetch(cur ^ 1, j + 1);
+        __builtin_amdgcn_sched_barrier(0);                 // the reads of step j + 1 are issued before the MFMAs of step j
+        int k = 0;
+#pragma unroll
+        for (int b1 = 0; b1 < NB; ++b1)
+#pragma unroll
+            for (int b2 = b1; b2 < NB; ++b2, ++k)
+                acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(op[cur][b1], op[cur][b2], acc[k], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    lin_barrier();                                         // every wave has read its last operand: the slot turns into scratch
+    float* scr = reinterpret_cast<float*>(slot);           // [wave][block][lane][4]: 16-byte lane-linear writes
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) *reinterpret_cast<f32x4*>(scr + ((wave * NBLK + k) * 64 + lane) * 4) = acc[k];
+    lin_barrier();
+    for (int o = t; o < NBLK * 256; o += LNT) {            // image element (row, col) of block k <- lane (row / 4) * 16 + col, register row % 4
+        const int k = o >> 8, row = (o >> 4) & 15, col = o & 15, src = ((k * 64 + (row >> 2) * 16 + col) << 2) + (row & 3);
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < LNW; ++w) sum += scr[w * NBLK * 256 + src];
+        if (SC1) st_sc1(out + o, sum); else out[o] = sum;
     }
 }
 
@@ -446,11 +498,11 @@ __global__ __launch_bounds__(LNT) void lin_step_kernel(const LinArgs a) {
 
 // ---- persistent form: up to kLinMaxPersist steps in one launch ----------------------------------------------------------------
 template <int NB, int DT, int LT>
-__global__ __launch_bounds__(LNT, 4) void lin_persist_kernel(const LinArgs a) {       // 4 waves per SIMD = two workgroups per CU
+__global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) {       // one workgroup per CU (its LDS request sees to that)
     extern __shared__ __attribute__((aligned(16))) char lin_smem[];
     const int b = blockIdx.x, t = threadIdx.x, N = a.n_steps;
     constexpr int NO = NB * (NB + 1) / 2 * 256;
-    const int per_set = a.n_reduce / kLinReduceSets;          // reducer workgroups per set = NO / 32
+    const int per_set = a.n_reduce / kLinReduceSets;          // reducer workgroups per set
     if (b < a.has_update) {
         // ---- the updater: one workgroup, parameters and Adam state in registers / LDS across all N steps -------------------
         LinUpd<NB, DT, LT> u;
@@ -460,54 +512,105 @@ __global__ __launch_bounds__(LNT, 4) void lin_persist_kernel(const LinArgs a) { 
         float g[LKOUT];
 #pragma unroll
         for (int k = 0; k < LKOUT; ++k) g[k] = 0.f;
+        LIN_STAMP(10);
+        unsigned long long tw0 = 0, tw1 = 0, twait = 0, twait_max = 0;
         for (int n = 0; n < N; ++n) {
             LIN_STAMP(0);
             u.publish_params();
-            lin_wait_count(a.cnt_reduce + n, (unsigned)per_set, a.status);     // (also the barrier behind publish_params)
+            LIN_STAMP(9);
+            LIN_NOW(tw0);
+            lin_wait_count(a.cnt_reduce + n, (unsigned)per_set, a.status, (1u << 28) | ((unsigned)n << 16));     // (also the barrier behind publish_params)
+            LIN_NOW(tw1);
+            twait += tw1 - tw0; twait_max = tw1 - tw0 > twait_max ? tw1 - tw0 : twait_max;
+            if (n == 0) LIN_PUT(13, tw1 - tw0);
+            LIN_PUT(11, twait); LIN_PUT(12, twait_max);
+            LIN_STAMP(8);
             u.template expand_M<true>(a.M_base + (long long)n * NO);
             __syncthreads();
             ++tstep;
             u.step(a, tstep, g);
             __syncthreads();                                   // everybody is done reading the LDS copies before they are refreshed
             LIN_STAMP(7);
+            { unsigned long long te = 0; LIN_NOW(te); LIN_PUT(64 + n, te); }
         }
         u.store_state(a, g, tstep);
     } else if (b < a.has_update + a.n_reduce) {
         // ---- reducers: set (rb / per_set) takes batches set, set + 2, ... ------------------------------------------------------
         const int rb = b - a.has_update, set = rb / per_set, ro = rb % per_set;
+        unsigned long long r0 = 0, r1 = 0, r2 = 0, racc_w = 0, racc_r = 0;
         for (int n = set; n < N; n += kLinReduceSets) {
-            lin_wait_count(a.cnt_stream + n, (unsigned)a.ntiles, a.status);
-            lin_reduce<true>(a.partial_base + (long long)n * a.ntiles * NO, a.M_base + (long long)n * NO, a.ntiles, lin_smem, ro, NO);
+            LIN_NOWQ(r0);
+            lin_wait_count(a.cnt_stream + n, (unsigned)a.ntiles, a.status, (2u << 28) | ((unsigned)n << 16));
+            LIN_NOWQ(r1);
+            if (!(a.diag & 1))
+                for (int sub = ro; sub < NO / 32; sub += per_set) {        // 32 outputs at a time
+                    if (sub != ro) __syncthreads();                     // the previous slice's LDS sums have been read
+                    lin_reduce<true>(a.partial_base + (long long)n * a.ntiles * NO, a.M_base + (long long)n * NO, a.ntiles, lin_smem, sub, NO);
+                }
             lin_wait_vmcnt<0>();                               // every storing wave drains its write-through stores ...
             __syncthreads();                                   // ... before the one lane that signals for the workgroup
+            LIN_NOWQ(r2);
+            racc_w += r1 - r0; racc_r += r2 - r1;
+            if (rb == 5) { LIN_PUT(40, racc_w); LIN_PUT(41, racc_r); }
             if (t == 0) __hip_atomic_fetch_add(a.cnt_reduce + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            { unsigned long long te = 0; LIN_NOW(te); LIN_PUTMAX(128 + n, te); }
         }
     } else {
-        // ---- streamers: tile `tile` of every batch; the loads of batch n + 1 are issued the moment batch n's products are done --
-        const int tile = b - a.has_update - a.n_reduce;
+        // ---- streamers: workgroup sid takes tiles sid, sid + S, ... of every batch, in batch order, through a ring of two LDS
+        // slots: the loads of work item i + 1 are in flight while item i is multiplied.  The batch pointers live in LDS (one
+        // fetch per launch: a scalar load per batch would sit on the critical path with the memory system busy).
+        const int sid = b - a.has_update - a.n_reduce, S = a.n_stream;
         const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
         const LinSlot sl(a.D, a.L);
-        lin_issue_tile(a, sl, a.xs[0], a.z1s[0], a.z2s[0], tile, lin_smem, t, wave);
-        for (int n = 0; n < N; ++n) {
-            lin_wait_vmcnt<0>();                               // tile n has landed; this wave's write-through stores of batch n - 1 are out
-            __syncthreads();
-            if (n >= 1 && t == 0) __hip_atomic_fetch_add(a.cnt_stream + (n - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            lin_fix_tile(a, sl, a.xs[n], a.z1s[n], a.z2s[n], tile, lin_smem, t);
-            lin_multiply_tile<NB, true>(a, sl, lin_smem, a.partial_base + ((long long)n * a.ntiles + tile) * NO, t, wave);
-            __syncthreads();                                   // every wave's products are done: the slot is free for the next tile
-            if (n + 1 < N) lin_issue_tile(a, sl, a.xs[n + 1], a.z1s[n + 1], a.z2s[n + 1], tile, lin_smem, t, wave);
+        const int stride = max(sl.bytes, lin_scratch_bytes(NB));        // a slot doubles as the multiply's cross-wave scratch
+        const float** tab = reinterpret_cast<const float**>(lin_smem + 2 * stride);            // [3][kLinMaxPersist]
+        if (t < 3 * kLinMaxPersist) {
+            const int which = t / kLinMaxPersist, n = t % kLinMaxPersist;
+            tab[t] = n < N ? (which == 0 ? a.xs : which == 1 ? a.z1s : a.z2s)[n] : nullptr;
+        }
+        __syncthreads();
+        const int per_batch = sid < a.ntiles ? (a.ntiles - sid + S - 1) / S : 0, items = N * per_batch;
+        auto item_batch = [&](int i) { return i / per_batch; };
+        auto item_tile = [&](int i) { return sid + (i % per_batch) * S; };
+        auto issue = [&](int i) {
+            const int n = item_batch(i);
+            lin_issue_tile(a, sl, tab[n], tab[kLinMaxPersist + n], tab[2 * kLinMaxPersist + n], item_tile(i), lin_smem + (i & 1) * stride, t, wave);
+        };
+        if (items > 0) issue(0);
+        unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, sacc_i = 0, sacc_l = 0, sacc_f = 0, sacc_m = 0;
+        for (int i = 0; i < items; ++i) {
+            // (the slot item i + 1 lands in was released by the barrier that closed iteration i - 1)
+            LIN_NOWQ(s0);
+            if (i + 1 < items) { issue(i + 1); LIN_NOWQ(s1); lin_wait_vmcnt_upto(sl.passes); } else lin_wait_vmcnt<0>();
+            // tile i has landed, and -- the counter retires in order -- so have this wave's write-through stores of item i - 1
+            lin_barrier();
+            LIN_NOWQ(s2);
+            if (i >= 1 && t == 0 && !(a.diag & 4)) __hip_atomic_fetch_add(a.cnt_stream + item_batch(i - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int n = item_batch(i), tile = item_tile(i);
+            char* slot = lin_smem + (i & 1) * stride;
+            lin_fix_tile(a, sl, tab[n], tab[kLinMaxPersist + n], tab[2 * kLinMaxPersist + n], tile, slot, t);
+            LIN_NOWQ(s3);
+            lin_multiply_tile<NB, true>(a, sl, slot, a.partial_base + ((long long)((a.diag & 2) ? 0 : n) * a.ntiles + tile) * NO, t, wave);
+            lin_barrier();                                     // every wave's products are done: the slot is free for item i + 2
+            LIN_NOWQ(s4);
+            if (i + 1 < items) { sacc_i += s1 - s0; sacc_l += s2 - s1; sacc_f += s3 - s2; sacc_m += s4 - s3; }
+            if (sid == 7) { LIN_PUT(42, sacc_i); LIN_PUT(43, sacc_l); LIN_PUT(44, sacc_f); LIN_PUT(45, sacc_m); LIN_PUT(46, (unsigned long long)items); }
         }
         lin_wait_vmcnt<0>();
         __syncthreads();
-        if (t == 0) __hip_atomic_fetch_add(a.cnt_stream + (N - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (items > 0 && t == 0) __hip_atomic_fetch_add(a.cnt_stream + item_batch(items - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-// device tables of batch pointers (the persistent kernel reads them; 48 pointers per launch keep the kernarg small)
-struct LinTable { const float* x[16]; const float* z1[16]; const float* z2[16]; int n, base; };
+// device tables of batch pointers (the persistent kernel reads them; 48 pointers per launch keep the kernarg small).  The
+// first table launch of a persistent launch also zeroes its arrival counters and status word (a kernel of this stream rather
+// than a memset node: it stays an ordinary kernel node when the call is captured into a hipGraph).
+struct LinTable { const float* x[16]; const float* z1[16]; const float* z2[16]; int n, base; unsigned* zero; };
 __global__ void lin_table_kernel(const LinTable tb, const float** xs, const float** z1s, const float** z2s) {
     const int i = threadIdx.x;
     if (i < tb.n) { xs[tb.base + i] = tb.x[i]; z1s[tb.base + i] = tb.z1[i]; z2s[tb.base + i] = tb.z2[i]; }
+    if (tb.zero)
+        for (int k = i; k < 1024; k += 64) tb.zero[k] = 0u;
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
@@ -519,14 +622,35 @@ bool lin_steps_supported(const vaek_ctx* c) {
     return c->cfg.n_enc_hidden == 0 && c->cfg.n_dec_hidden == 0 && !c->cfg.sigmoid_decoder && c->cfg.dtype == VAEK_F32 &&
            c->cfg.world == 1 && c->L + 2 * c->D + 1 <= 64 && (long long)c->B * std::min(c->D, c->L) >= 8;
 }
+static size_t lin_slot_stride(const vaek_ctx* c) {      // one tile slot, large enough to double as the multiply's cross-wave scratch
+    const LinSlot sl(c->D, c->L);
+    return std::max((size_t)sl.bytes, (size_t)lin_scratch_bytes(lin_nb(c)));
+}
 static size_t lin_lds_need(const vaek_ctx* c) {
     const int NB = lin_nb(c), D = c->D, L = c->L;
-    const LinSlot sl(D, L);
+    struct { size_t bytes; } sl{lin_slot_stride(c)};
     const size_t upd = NB == 3 ? LinUpd<3, 0, 0>::lds_bytes(D, L) : LinUpd<4, 0, 0>::lds_bytes(D, L);
     return std::max((size_t)sl.bytes, std::max(upd, (size_t)16 * 32 * sizeof(double))) + 64;
 }
-// the persistent form needs two workgroups per CU (1 + 96 + 256 resident workgroups at the metric's size): <= 78 KB of LDS each
-static bool lin_persist_supported(const vaek_ctx* c) { return lin_steps_supported(c) && lin_nb(c) == 3 && lin_lds_need(c) <= 78 * 1024; }
+// The persistent form gives every workgroup a CU of its own (the updater's float64 chains and the streamers' MFMA loops both
+// lose a factor ~2 when they share one): each workgroup asks for more than half a CU's LDS -- the streamers need it anyway for
+// their ring of two tile slots + the batch pointer tables -- and the grid stays within the CU count.
+static size_t lin_persist_lds(const vaek_ctx* c) {
+    const LinSlot sl(c->D, c->L);
+    const size_t ring = 2 * lin_slot_stride(c) + 3 * kLinMaxPersist * sizeof(void*) + 64;
+    return std::max(std::max(lin_lds_need(c), ring), (size_t)82 * 1024);
+}
+static bool lin_persist_supported(const vaek_ctx* c) {
+    const LinSlot sl(c->D, c->L);
+    return lin_steps_supported(c) && lin_nb(c) == 3 && lin_persist_lds(c) <= 160 * 1024 && sl.passes <= 12 &&
+           c->n_cu >= 1 + kLinReduceSets * kLinReduceWgs + 16;
+}
+// streamer workgroups of the persistent launch: the CUs the updater and the reducers leave, tiles dealt evenly
+static int lin_persist_streamers(const vaek_ctx* c) {
+    const int ntiles = (c->B + 255) / 256, smax = c->n_cu - 1 - kLinReduceSets * kLinReduceWgs;
+    const int per = (ntiles + smax - 1) / smax;
+    return (ntiles + per - 1) / per;
+}
 
 struct LinWs { float* partial; double* M; unsigned* cnt; const float** tab; size_t total; };
 static LinWs lin_carve(const vaek_ctx* c, char* base) {
@@ -534,7 +658,7 @@ static LinWs lin_carve(const vaek_ctx* c, char* base) {
     const int slots = lin_persist_supported(c) ? kLinMaxPersist : 2;
     LinWs w{};
     size_t off = 0;
-    w.cnt = reinterpret_cast<unsigned*>(base + off); off += 4096;                 // cnt_stream[64] | cnt_reduce[64] | status, one memset
+    w.cnt = reinterpret_cast<unsigned*>(base + off); off += 4096;                 // cnt_stream[64] | cnt_reduce[64] | status, zeroed by lin_table_kernel
     w.tab = reinterpret_cast<const float**>(base + off); off += 3 * kLinMaxPersist * sizeof(void*) + 256;
     w.M = reinterpret_cast<double*>(base + off); off += (size_t)slots * no * sizeof(double) + 256;
     w.partial = reinterpret_cast<float*>(base + off); off += (size_t)slots * ntiles * no * sizeof(float) + 256;
@@ -561,29 +685,33 @@ int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v
     const int which = (c->D == 12 && c->L == 20) ? 0 : (NB <= 3 ? 1 : 2);
     static const char* env = getenv("VAEK_LIN_PERSIST");              // diagnostic: 0 forces the launch-per-step form
     const bool persistent = lin_persist_supported(c) && !(env && atoi(env) == 0);
-    const size_t lds = lin_lds_need(c);
+    const size_t lds = persistent ? lin_persist_lds(c) : lin_lds_need(c);
     const LinKernel fn = persistent ? (which == 0 ? lin_persist_kernel<3, 12, 20> : lin_persist_kernel<3, 0, 0>)
                                     : (which == 0 ? lin_step_kernel<3, 12, 20> : which == 1 ? lin_step_kernel<3, 0, 0> : lin_step_kernel<4, 0, 0>);
     static thread_local bool attr_set[2][3] = {};
     if (!attr_set[persistent ? 1 : 0][which]) {
-        VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));   // a cap, not a request
         attr_set[persistent ? 1 : 0][which] = true;
     }
     if (persistent) {
         for (int s0 = 0; s0 < n_steps; s0 += kLinMaxPersist) {
             const int n = std::min(kLinMaxPersist, n_steps - s0);
-            VAEK_HIP_CHECK(hipMemsetAsync(w.cnt, 0, 4096, st));
             const float** txs = w.tab; const float** tz1 = w.tab + kLinMaxPersist; const float** tz2 = w.tab + 2 * kLinMaxPersist;
             for (int b0 = 0; b0 < n; b0 += 16) {
                 LinTable tb{};
-                tb.n = std::min(16, n - b0); tb.base = b0;
+                tb.n = std::min(16, n - b0); tb.base = b0; tb.zero = b0 == 0 ? w.cnt : nullptr;
                 for (int i = 0; i < tb.n; ++i) { tb.x[i] = xs[s0 + b0 + i]; tb.z1[i] = z1s[s0 + b0 + i]; tb.z2[i] = z2s[s0 + b0 + i]; }
                 hipLaunchKernelGGL(lin_table_kernel, dim3(1), dim3(64), 0, st, tb, txs, tz1, tz2);
             }
             LinArgs a{};
             lin_fill_common(c, a, params, grads, m, v, step_dev, lr);
             a.persistent = 1; a.n_steps = n;
-            a.has_update = 1; a.n_reduce = kLinReduceSets * (no / 32); a.n_stream = ntiles;
+            static const int rwg = getenv("VAEK_LIN_RWG") ? atoi(getenv("VAEK_LIN_RWG")) : kLinReduceWgs;     // diagnostic override
+            a.has_update = 1; a.n_reduce = kLinReduceSets * std::min(rwg, no / 32); a.n_stream = lin_persist_streamers(c);
+            static const int proles = getenv("VAEK_LIN_ROLES") ? atoi(getenv("VAEK_LIN_ROLES")) : 7;    // diagnostic (tools/lin_roles.sh)
+            a.diag = getenv("VAEK_LIN_DIAG") ? atoi(getenv("VAEK_LIN_DIAG")) : 0;
+            if (!(proles & 4)) a.has_update = 0;
+            if (!(proles & 2)) { a.has_update = 0; a.n_reduce = 0; }
             a.xs = txs; a.z1s = tz1; a.z2s = tz2;
             a.partial_base = w.partial; a.M_base = w.M;
             a.cnt_stream = w.cnt; a.cnt_reduce = w.cnt + 256; a.status = w.cnt + 512;
@@ -592,6 +720,11 @@ int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v
         }
         VAEK_HIP_CHECK(hipGetLastError());
         return VAEK_OK;
+    }
+    {   // no in-launch waits in this form: the status word reads "never gave up"
+        LinTable tb{};
+        tb.zero = w.cnt;
+        hipLaunchKernelGGL(lin_table_kernel, dim3(1), dim3(64), 0, st, tb, w.tab, w.tab + kLinMaxPersist, w.tab + 2 * kLinMaxPersist);
     }
     static const int roles = getenv("VAEK_LIN_ROLES") ? atoi(getenv("VAEK_LIN_ROLES")) : 7;   // diagnostic: 1 stream, 2 reduce, 4 update
     const size_t pstride = (size_t)ntiles * no;
@@ -619,7 +752,7 @@ int lin_steps_status(vaek_ctx* c, void* ws, int* gave_up) {
     const LinWs w = lin_carve(c, static_cast<char*>(ws) + c->ws_lin);
     unsigned s = 0;
     VAEK_HIP_CHECK(hipMemcpy(&s, w.cnt + 512, sizeof(s), hipMemcpyDeviceToHost));
-    *gave_up = s != 0;
+    *gave_up = (int)s;
     return VAEK_OK;
 }
 

@@ -142,7 +142,8 @@ class Engine:
         """Synchronous: True if a bounded wait inside vaek_train_steps' persistent launch ever expired."""
         f = C.c_int32()
         _lib.check(self.lib.vaek_train_steps_status(self.h, _ptr(self.workspace), C.byref(f)))
-        return bool(f.value)
+        self.train_steps_status_word = f.value & 0xffffffff
+        return f.value != 0
 
     def grads_only(self, params, grads, step_dev, x, z1, z2):
         _lib.check(self.lib.vaek_train_step_grads_only(self.h, _ptr(params), _ptr(grads), _ptr(step_dev), _ptr(x),
