@@ -44,6 +44,7 @@
 namespace vaek {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using d2 = __attribute__((ext_vector_type(2))) double;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
@@ -358,6 +359,26 @@ struct LinUpd {
             Mf[(16 * b2 + j) * NFP + 16 * b1 + i] = val;   // (diagonal blocks are bitwise symmetric: same products, same order)
         }
     }
+    // the same in two halves (persistent form): the loads of batch n + 1's M ride under step n when its reducers are already done
+    static constexpr int MPT = (NBLK * 256 + LNT - 1) / LNT;
+    __device__ __forceinline__ void fetch_M(const double* M_in, double (&r)[MPT]) {
+#pragma unroll
+        for (int k = 0; k < MPT; ++k) r[k] = ld_sc1(M_in + min((int)threadIdx.x + LNT * k, NBLK * 256 - 1));
+    }
+    __device__ __forceinline__ void scatter_M(const double (&r)[MPT]) {
+#pragma unroll
+        for (int k = 0; k < MPT; ++k) {
+            const int e = threadIdx.x + LNT * k;
+            if (e < NBLK * 256) {
+                const int blk = e >> 8, i = (e >> 4) & 15, j = e & 15;
+                int b1 = 0, rem = blk;
+                while (rem >= NB - b1) { rem -= NB - b1; ++b1; }
+                const int b2 = b1 + rem;
+                Mf[(16 * b1 + i) * NFP + 16 * b2 + j] = r[k];
+                Mf[(16 * b2 + j) * NFP + 16 * b1 + i] = r[k];
+            }
+        }
+    }
     // one step: Mf and the parameter copies are in LDS (a barrier behind them); returns with this thread's p / m / v updated,
     // its gradients in gout[], and nothing in LDS that the next publish_params / expand_M may not overwrite after a barrier
     __device__ __forceinline__ void step(const LinArgs& a, int tstep, float (&gout)[LKOUT]) {
@@ -365,6 +386,71 @@ struct LinUpd {
         const double eps = off_eps >= 0 ? epsv[0] * (double)a.eps_cli : (double)a.eps_cli;
         const double sigma = exp(0.5 * eps), inv_var = 1.0 / (sigma * sigma);       // (one float64 exp on the chain, not two)
         LIN_STAMP(1);
+        if constexpr (DT > 0 && LT > 0 && (DT % 2 == 0) && (LT % 2 == 0) && LT * (NFP / 2) <= LNT && LT * DT <= LNT / 2) {
+            // The metric's shape.  Each thread owns 2 (SM, P1) or 4 (G) neighbouring columns of one output row, so that the M / SM /
+            // P1 operands arrive as 16-byte LDS reads, every phase is ONE round of the workgroup, and all operands of a thread
+            // are in registers before its first FMA (hipcc otherwise waits out the LDS latency once per product).
+            constexpr int HP = NFP / 2;
+            {   // SM = S M: thread (l, f .. f + 1)
+                const int l = min(t / HP, LT - 1), f = (t % HP) * 2;
+                double w[DT + 2]; d2 mv[DT + 2];
+                w[0] = sd[l]; mv[0] = *reinterpret_cast<const d2*>(Mf + l * NFP + f);
+                w[1] = bed[l]; mv[1] = *reinterpret_cast<const d2*>(Mf + fone * NFP + f);
+#pragma unroll
+                for (int dd = 0; dd < DT; ++dd) { w[2 + dd] = Wed[dd * LT + l]; mv[2 + dd] = *reinterpret_cast<const d2*>(Mf + (LT + dd) * NFP + f); }
+                __builtin_amdgcn_sched_barrier(0);
+                d2 s2 = w[0] * mv[0];
+#pragma unroll
+                for (int k = 1; k < DT + 2; ++k) s2 += w[k] * mv[k];
+                if (t < LT * HP) *reinterpret_cast<d2*>(SM + l * NFP + f) = s2;
+            }
+            __syncthreads();
+            LIN_STAMP(2);
+            {   // P1 = R M: thread (d, f .. f + 1)
+                const int d = min(t / HP, DT - 1), f = (t % HP) * 2;
+                double w[LT + 1]; d2 mv[LT + 3];
+                mv[LT] = *reinterpret_cast<const d2*>(Mf + (LT + DT + d) * NFP + f);
+                mv[LT + 1] = *reinterpret_cast<const d2*>(Mf + (LT + d) * NFP + f);
+                mv[LT + 2] = *reinterpret_cast<const d2*>(Mf + fone * NFP + f);
+                w[LT] = bdd[d];
+#pragma unroll
+                for (int l = 0; l < LT; ++l) { w[l] = Wdd[l * DT + d]; mv[l] = *reinterpret_cast<const d2*>(SM + l * NFP + f); }
+                __builtin_amdgcn_sched_barrier(0);
+                d2 s2 = sigma * mv[LT] - mv[LT + 1] + w[LT] * mv[LT + 2];
+#pragma unroll
+                for (int l = 0; l < LT; ++l) s2 += w[l] * mv[l];
+                if (t < DT * HP) *reinterpret_cast<d2*>(P1 + d * NFP + f) = s2;
+            }
+            __syncthreads();
+            LIN_STAMP(3);
+            if (t < LNT / 2) {   // G = Wd P1: thread (l, f .. f + 3), the lower half of the workgroup
+                constexpr int QP = NFP / 4;
+                const int l = min(t / QP, LT - 1), f = (t % QP) * 4;
+                d2 wv[DT / 2], pa[DT], pb[DT];
+#pragma unroll
+                for (int d = 0; d < DT / 2; ++d) wv[d] = *reinterpret_cast<const d2*>(Wdd + l * DT + 2 * d);
+#pragma unroll
+                for (int d = 0; d < DT; ++d) { pa[d] = *reinterpret_cast<const d2*>(P1 + d * NFP + f); pb[d] = *reinterpret_cast<const d2*>(P1 + d * NFP + f + 2); }
+                __builtin_amdgcn_sched_barrier(0);
+                d2 sa = {0.0, 0.0}, sb = {0.0, 0.0};
+#pragma unroll
+                for (int d = 0; d < DT; ++d) { const double wd = wv[d / 2][d & 1]; sa += wd * pa[d]; sb += wd * pb[d]; }
+                if (t < LT * QP) { *reinterpret_cast<d2*>(G + l * NFP + f) = sa; *reinterpret_cast<d2*>(G + l * NFP + f + 2) = sb; }
+            } else {             // dwd[l][d] = S[l,:] . P1[d,:]: the upper half
+                const int e = min(t - LNT / 2, LT * DT - 1), l = e / DT, d = e % DT;
+                double w[DT]; d2 pv[DT / 2];
+                const double s_l = sd[l], b_l = bed[l], p_l = P1[d * NFP + l], p_o = P1[d * NFP + fone];
+#pragma unroll
+                for (int dd = 0; dd < DT; ++dd) w[dd] = Wed[dd * LT + l];
+#pragma unroll
+                for (int dd = 0; dd < DT / 2; ++dd) pv[dd] = *reinterpret_cast<const d2*>(P1 + d * NFP + LT + 2 * dd);
+                __builtin_amdgcn_sched_barrier(0);
+                double sx = s_l * p_l + b_l * p_o;
+#pragma unroll
+                for (int dd = 0; dd < DT; ++dd) sx += w[dd] * pv[dd / 2][dd & 1];
+                if (t - LNT / 2 < LT * DT) dwd[e] = sx;
+            }
+        } else {
         for (int e = t; e < L * NFP; e += LNT) {              // SM = S M
             const int l = e / NFP, f = e % NFP;
             double s = sd[l] * Mf[l * NFP + f] + bed[l] * Mf[fone * NFP + f];
@@ -397,8 +483,42 @@ struct LinUpd {
             for (int dd = 0; dd < (DT ? DT : 32); ++dd) if (DT || dd < D) s += Wed[dd * L + l] * P1[d * NFP + L + dd];
             dwd[e] = s;
         }
+        }
         __syncthreads();
         LIN_STAMP(4);
+        double ssq = 0.0, musq = 0.0, z2r = 0.0, klc = 0.0;
+        if constexpr (DT > 0 && LT > 0 && (DT % 2 == 0) && (LT % 2 == 0) && LT * (NFP / 2) <= LNT && LT * DT <= LNT / 2) {
+            // Only d loss / d epsilon and the three loss means need the four scalar sums, and wave 0 owns those outputs (index
+            // P - 1 .. P + 2 < LNT + 64): it forms the sums by itself -- strided shares per lane, operands batched, xor-shuffles --
+            // while the other waves are already at their gradients and Adam.  No barrier, no workgroup-wide reduction.
+            static_assert(DT * LT + LT + LT * DT + DT + LT + 1 + 3 <= LNT + 64, "wave 0 must own the scalar outputs");
+            if (t < 64) {
+                constexpr int NS = (LT * DT + 63) / 64, NM = (LT * (DT + 1) + 63) / 64;
+                double wa[NS], da[NS], qw[NM], qs[NM], qd[NM], qm[NM];
+#pragma unroll
+                for (int j = 0; j < NS; ++j) { const int e = min(t + 64 * j, LT * DT - 1); wa[j] = Wdd[e]; da[j] = dwd[e]; }
+#pragma unroll
+                for (int j = 0; j < NM; ++j) {
+                    const int e = min(t + 64 * j, LT * (DT + 1) - 1), l = e / (DT + 1), dd = e % (DT + 1), f = dd < DT ? LT + dd : fone;
+                    qw[j] = dd < DT ? Wed[dd * LT + l] : bed[l]; qs[j] = SM[l * NFP + f]; qd[j] = sd[l]; qm[j] = Mf[l * NFP + f];
+                }
+                const int dq = min(t, DT - 1), lq = min(t, LT - 1);
+                const double px = P1[dq * NFP + LT + dq], pz = P1[dq * NFP + LT + DT + dq], po = P1[dq * NFP + fone], bq = bdd[dq];
+                const double lvq = lvd[lq], evq = elv[lq];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < NS; ++j) ssq += t + 64 * j < LT * DT ? wa[j] * da[j] : 0.0;
+#pragma unroll
+                for (int j = 0; j < NM; ++j) musq += t + 64 * j < LT * (DT + 1) ? qw[j] * (qs[j] - qd[j] * qm[j]) : 0.0;
+                if (t < DT) { ssq += -px + sigma * pz + bq * po; z2r = pz; }
+                if (t < LT) klc = 1.0 + lvq - evq;                                     // 1 + lv - e^{lv}
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    ssq += __shfl_xor(ssq, o, 64); musq += __shfl_xor(musq, o, 64);
+                    z2r += __shfl_xor(z2r, o, 64); klc += __shfl_xor(klc, o, 64);
+                }
+            }
+        } else {
         // the four scalar sums: each thread a strided share, lanes by xor-shuffle, the waves in order (all fixed order)
         double p_ssq = 0.0, p_musq = 0.0, p_z2r = 0.0, p_klc = 0.0;
         for (int e = t; e < L * D; e += LNT) p_ssq += Wdd[e] * dwd[e];
@@ -420,10 +540,10 @@ struct LinUpd {
         }
         if ((t & 63) == 0) { red[t >> 6] = p_ssq; red[LNW + (t >> 6)] = p_musq; red[2 * LNW + (t >> 6)] = p_z2r; red[3 * LNW + (t >> 6)] = p_klc; }
         __syncthreads();
-        LIN_STAMP(5);
-        double ssq = 0.0, musq = 0.0, z2r = 0.0, klc = 0.0;
 #pragma unroll
         for (int w = 0; w < LNW; ++w) { ssq += red[w]; musq += red[LNW + w]; z2r += red[2 * LNW + w]; klc += red[3 * LNW + w]; }
+        }
+        LIN_STAMP(5);
         const double inv_bt = (double)a.inv_bt, rows = (double)a.rows, c0 = inv_var * inv_bt;
         const float bc1 = -expm1f((float)tstep * -0.10536051565782628f), bc2 = -expm1f((float)tstep * -0.0010005003335835335f);
 #pragma unroll
@@ -514,19 +634,32 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) { 
         for (int k = 0; k < LKOUT; ++k) g[k] = 0.f;
         LIN_STAMP(10);
         unsigned long long tw0 = 0, tw1 = 0, twait = 0, twait_max = 0;
+        double mreg[LinUpd<NB, DT, LT>::MPT];
+        bool pre_ok = false;                                   // (uniform) mreg already holds this batch's M
         for (int n = 0; n < N; ++n) {
             LIN_STAMP(0);
             u.publish_params();
             LIN_STAMP(9);
             LIN_NOW(tw0);
-            lin_wait_count(a.cnt_reduce + n, (unsigned)per_set, a.status, (1u << 28) | ((unsigned)n << 16));     // (also the barrier behind publish_params)
+            if (!pre_ok) {
+                lin_wait_count(a.cnt_reduce + n, (unsigned)per_set, a.status, (1u << 28) | ((unsigned)n << 16));     // (also the barrier behind publish_params)
+                u.fetch_M(a.M_base + (long long)n * NO, mreg);
+            } else {
+                __syncthreads();
+            }
             LIN_NOW(tw1);
             twait += tw1 - tw0; twait_max = tw1 - tw0 > twait_max ? tw1 - tw0 : twait_max;
             if (n == 0) LIN_PUT(13, tw1 - tw0);
             LIN_PUT(11, twait); LIN_PUT(12, twait_max);
             LIN_STAMP(8);
-            u.template expand_M<true>(a.M_base + (long long)n * NO);
+            u.scatter_M(mreg);
+            // are the reducers of the next batch done already?  (they usually are: the streamers run ahead.)  Then its M is loaded
+            // now and travels under this step's arithmetic; otherwise the top of the next iteration waits as usual.
+            if (t == 0)
+                u.epsv[1] = (n + 1 < N && __hip_atomic_load(a.cnt_reduce + n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)per_set) ? 1.0 : 0.0;
             __syncthreads();
+            pre_ok = u.epsv[1] != 0.0;
+            if (pre_ok) u.fetch_M(a.M_base + (long long)(n + 1) * NO, mreg);
             ++tstep;
             u.step(a, tstep, g);
             __syncthreads();                                   // everybody is done reading the LDS copies before they are refreshed
