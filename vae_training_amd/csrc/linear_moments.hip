@@ -57,7 +57,7 @@ constexpr int kLinReduceWgs = 12;                 // workgroups per set, each su
 struct LinArgs {
     // roles by blockIdx.x: [0, has_update) the updater, then n_reduce reducers, then n_stream streamers
     int has_update, n_reduce, n_stream;
-    int B, D, L, ntiles;
+    int B, D, L, ntiles, T;                       // T: samples per tile (a multiple of 32, <= 512)
     // ---- launch-per-step form: streamers take THE batch of this launch, reducers the one before, the updater the one before that
     const float* x; const float* z1; const float* z2; float* partial_out;        // [ntiles][NBLK * 256]
     const float* partial_in; double* M_out;                                       // [NBLK * 256]
@@ -156,21 +156,21 @@ __device__ __forceinline__ void lin_wait_count(const unsigned* cnt, unsigned tar
 }
 
 // ---- streamer pieces ------------------------------------------------------------------------------------------------------------
-// LDS slot of one 256-sample tile: the three tensors' tiles exactly as they lie in HBM (row-major [256][L] / [256][D]), each
+// LDS slot of one T-sample tile: the three tensors' tiles exactly as they lie in HBM (row-major [T][L] / [T][D]), each
 // padded to whole 8 KB (one pass of the 512-thread copy: every thread issues the same number of loads), the validity column
-// V[256] (the "1" feature; 0 for rows past the batch end) and a zero word.
+// V[T] (the "1" feature; 0 for rows past the batch end) and a zero word.
 struct LinSlot {
     int z1_b, x_b, oX, oZ2, oV, oC, bytes, passes;
-    __device__ __host__ LinSlot(int D, int L) {
-        z1_b = (L * 1024 + 8191) / 8192 * 8192; x_b = (D * 1024 + 8191) / 8192 * 8192;
-        oX = z1_b; oZ2 = oX + x_b; oV = oZ2 + x_b; oC = oV + 1024; bytes = (oC + 16 + 255) / 256 * 256;
+    __device__ __host__ LinSlot(int D, int L, int T) {
+        z1_b = (L * 4 * T + 8191) / 8192 * 8192; x_b = (D * 4 * T + 8191) / 8192 * 8192;
+        oX = z1_b; oZ2 = oX + x_b; oV = oZ2 + x_b; oC = oV + 4 * T; bytes = (oC + 16 + 255) / 256 * 256;
         passes = (z1_b + 2 * x_b) / 8192;
     }
 };
 
 __device__ __forceinline__ void lin_issue_tile(const LinArgs& a, const LinSlot& sl, const float* x, const float* z1, const float* z2,
                                                int tile, char* slot, int t, int wave) {
-    const long long row0 = (long long)tile * 256;
+    const long long row0 = (long long)tile * a.T;
     auto copy = [&](const float* src, int cols, int bytes, int lds_off) {
         const long long tot = (long long)a.B * cols * 4, base = row0 * cols * 4;
         for (int i = 0; i < bytes / 8192; ++i) {
@@ -189,23 +189,24 @@ __device__ __forceinline__ void lin_issue_tile(const LinArgs& a, const LinSlot& 
 // after the tile has landed: the validity column, the zero word, and for the last tile of a ragged batch the rows past the end
 __device__ __forceinline__ void lin_fix_tile(const LinArgs& a, const LinSlot& sl, const float* x, const float* z1, const float* z2,
                                              int tile, char* slot, int t) {
-    const long long row0 = (long long)tile * 256;
-    const int valid = (int)min(256ll, (long long)a.B - row0), D = a.D, L = a.L;
-    if (t < 256) reinterpret_cast<float*>(slot + sl.oV)[t] = t < valid ? 1.f : 0.f;
+    const int T = a.T;
+    const long long row0 = (long long)tile * T;
+    const int valid = (int)min((long long)T, (long long)a.B - row0), D = a.D, L = a.L;
+    if (t < T) reinterpret_cast<float*>(slot + sl.oV)[t] = t < valid ? 1.f : 0.f;
     if (t == 0) *reinterpret_cast<float*>(slot + sl.oC) = 0.f;
-    if (valid < 256) {
+    if (valid < T) {
         auto patch_tail = [&](const float* src, int cols, int lds_off) {     // floats behind the tensor's last whole 16 bytes
             const long long tot = (long long)a.B * cols * 4, full = tot & ~15ll, base = row0 * cols * 4;
             if (t < (int)((tot - full) / 4) && full >= base) reinterpret_cast<float*>(slot + lds_off)[(full - base) / 4 + t] = src[full / 4 + t];
         };
         patch_tail(z1, L, 0); patch_tail(x, D, sl.oX); patch_tail(z2, D, sl.oZ2);
-        for (int e = valid * L + t; e < 256 * L; e += LNT) reinterpret_cast<float*>(slot)[e] = 0.f;
-        for (int e = valid * D + t; e < 256 * D; e += LNT) { reinterpret_cast<float*>(slot + sl.oX)[e] = 0.f; reinterpret_cast<float*>(slot + sl.oZ2)[e] = 0.f; }
+        for (int e = valid * L + t; e < T * L; e += LNT) reinterpret_cast<float*>(slot)[e] = 0.f;
+        for (int e = valid * D + t; e < T * D; e += LNT) { reinterpret_cast<float*>(slot + sl.oX)[e] = 0.f; reinterpret_cast<float*>(slot + sl.oZ2)[e] = 0.f; }
     }
     lin_barrier();
 }
 
-// M_tile = U^T U.  The SAMPLES are dealt to the waves: wave w takes samples 32 w .. 32 w + 31 -- 8 k-steps of 4 samples -- for
+// M_tile = U^T U.  The SAMPLES are dealt to the waves: wave w takes samples (T / 8) w .. -- T / 32 k-steps of 4 samples -- for
 // every block of the upper block triangle, so each operand register read from LDS feeds NB (+1) MFMAs, the matrix pipes of
 // the four SIMDs carry equal loads and the NBLK accumulator chains are independent.  The eight per-wave images are then
 // summed through LDS (in wave order: deterministic) in the tile's own slot, which is dead by then, and leave as one image.
@@ -228,29 +229,38 @@ __device__ __forceinline__ void lin_multiply_tile(const LinArgs& a, const LinSlo
     f32x4 acc[NBLK];
 #pragma unroll
     for (int k = 0; k < NBLK; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // k-step j of this wave: lane group g takes sample 32 w + 16 (j >> 2) + (j & 3) + 4 g.  The four samples of a step lie 4 rows
-    // apart: with 80- and 48-byte rows that is 16 banks, so the lane groups one ds_read_b32 services together never collide.
+    // Wave w takes samples (T / 8) w .. + T / 8 - 1 in J = T / 32 k-steps of 4.  Within a run of 16 samples lane group g takes sample
+    // s + 4 g in step s: four rows apart, i.e. 16 banks with 80- and 48-byte rows, so the lane groups one ds_read_b32 services
+    // together never collide; a run shorter than 16 (T / 8 not a multiple of 16: its last r < 4 steps) takes s + r g.
     // Operands run one step ahead in a second register set, and the scheduler is told to keep it that way: left alone hipcc
     // reuses one register set and waits out the full LDS latency before every MFMA.
+    const int J = a.T >> 5, wbase = (a.T >> 3) * wave, jfull = J & ~3;
     float op[2][NB];
     auto fetch = [&](int set, int j) {
-        const int sample = 32 * wave + 16 * (j >> 2) + (j & 3) + 4 * g;
+        const int sample = wbase + (j < jfull ? 16 * (j >> 2) + (j & 3) + 4 * g : 4 * jfull + (j - jfull) + (J - jfull) * g);
 #pragma unroll
         for (int u = 0; u < NB; ++u) op[set][u] = *reinterpret_cast<const float*>(slot + fb[u] + sample * fs[u]);
     };
-    fetch(0, 0);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int cur = j & 1;
-        if (j + 1 < 8) fetch(cur ^ 1, j + 1);
-        __builtin_amdgcn_sched_barrier(0);                 // the reads of step j + 1 are issued before the MFMAs of step j
+    auto products = [&](int set) {
         int k = 0;
 #pragma unroll
         for (int b1 = 0; b1 < NB; ++b1)
 #pragma unroll
             for (int b2 = b1; b2 < NB; ++b2, ++k)
-                acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(op[cur][b1], op[cur][b2], acc[k], 0, 0, 0);
+                acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(op[set][b1], op[set][b2], acc[k], 0, 0, 0);
+    };
+    fetch(0, 0);
+    for (int j = 0; j < J; j += 2) {
+        if (j + 1 < J) fetch(1, j + 1);
+        __builtin_amdgcn_sched_barrier(0);                 // the reads of step j + 1 are issued before the MFMAs of step j
+        products(0);
         __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < J) {
+            if (j + 2 < J) fetch(0, j + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            products(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     lin_barrier();                                         // every wave has read its last operand: the slot turns into scratch
     float* scr = reinterpret_cast<float*>(slot);           // [wave][block][lane][4]: 16-byte lane-linear writes
@@ -607,7 +617,7 @@ __global__ __launch_bounds__(LNT) void lin_step_kernel(const LinArgs a) {
     } else {
         const int tile = b - a.has_update - a.n_reduce;
         const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-        const LinSlot sl(a.D, a.L);
+        const LinSlot sl(a.D, a.L, a.T);
         lin_issue_tile(a, sl, a.x, a.z1, a.z2, tile, lin_smem, t, wave);
         lin_wait_vmcnt<0>();
         __syncthreads();
@@ -694,7 +704,7 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) { 
         // fetch per launch: a scalar load per batch would sit on the critical path with the memory system busy).
         const int sid = b - a.has_update - a.n_reduce, S = a.n_stream;
         const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-        const LinSlot sl(a.D, a.L);
+        const LinSlot sl(a.D, a.L, a.T);
         const int stride = max(sl.bytes, lin_scratch_bytes(NB));        // a slot doubles as the multiply's cross-wave scratch
         const float** tab = reinterpret_cast<const float**>(lin_smem + 2 * stride);            // [3][kLinMaxPersist]
         if (t < 3 * kLinMaxPersist) {
@@ -755,39 +765,50 @@ bool lin_steps_supported(const vaek_ctx* c) {
     return c->cfg.n_enc_hidden == 0 && c->cfg.n_dec_hidden == 0 && !c->cfg.sigmoid_decoder && c->cfg.dtype == VAEK_F32 &&
            c->cfg.world == 1 && c->L + 2 * c->D + 1 <= 64 && (long long)c->B * std::min(c->D, c->L) >= 8;
 }
+static size_t lin_ring_bytes(const vaek_ctx* c, int T) {        // the streamers' two tile slots (each doubling as the multiply's scratch) + pointer tables
+    const LinSlot sl(c->D, c->L, T);
+    return 2 * std::max((size_t)sl.bytes, (size_t)lin_scratch_bytes(lin_nb(c))) + 3 * kLinMaxPersist * sizeof(void*) + 64;
+}
+// Samples per tile.  256, unless a slightly taller tile lets every streamer of the persistent launch take exactly ONE tile per
+// batch (the metric: 65 536 samples = 228 tiles of 288 on the 231 CUs the updater and the reducers leave).
+static int lin_tile_rows(const vaek_ctx* c) {
+    const int smax = c->n_cu - 1 - kLinReduceSets * kLinReduceWgs;
+    if (smax < 16 || c->B <= 256 * smax) return 256;
+    const int T = 32 * (int)(((long long)c->B + 32ll * smax - 1) / (32ll * smax));
+    const LinSlot sl(c->D, c->L, T);
+    return T <= 512 && sl.passes <= 12 && lin_ring_bytes(c, T) <= 160 * 1024 ? T : 256;
+}
+static int lin_ntiles(const vaek_ctx* c) { const int T = lin_tile_rows(c); return (c->B + T - 1) / T; }
 static size_t lin_slot_stride(const vaek_ctx* c) {      // one tile slot, large enough to double as the multiply's cross-wave scratch
-    const LinSlot sl(c->D, c->L);
+    const LinSlot sl(c->D, c->L, lin_tile_rows(c));
     return std::max((size_t)sl.bytes, (size_t)lin_scratch_bytes(lin_nb(c)));
 }
 static size_t lin_lds_need(const vaek_ctx* c) {
     const int NB = lin_nb(c), D = c->D, L = c->L;
-    struct { size_t bytes; } sl{lin_slot_stride(c)};
     const size_t upd = NB == 3 ? LinUpd<3, 0, 0>::lds_bytes(D, L) : LinUpd<4, 0, 0>::lds_bytes(D, L);
-    return std::max((size_t)sl.bytes, std::max(upd, (size_t)16 * 32 * sizeof(double))) + 64;
+    return std::max(lin_slot_stride(c), std::max(upd, (size_t)16 * 32 * sizeof(double))) + 64;
 }
 // The persistent form gives every workgroup a CU of its own (the updater's float64 chains and the streamers' MFMA loops both
 // lose a factor ~2 when they share one): each workgroup asks for more than half a CU's LDS -- the streamers need it anyway for
 // their ring of two tile slots + the batch pointer tables -- and the grid stays within the CU count.
 static size_t lin_persist_lds(const vaek_ctx* c) {
-    const LinSlot sl(c->D, c->L);
-    const size_t ring = 2 * lin_slot_stride(c) + 3 * kLinMaxPersist * sizeof(void*) + 64;
-    return std::max(std::max(lin_lds_need(c), ring), (size_t)82 * 1024);
+    return std::max(std::max(lin_lds_need(c), lin_ring_bytes(c, lin_tile_rows(c))), (size_t)82 * 1024);
 }
 static bool lin_persist_supported(const vaek_ctx* c) {
-    const LinSlot sl(c->D, c->L);
+    const LinSlot sl(c->D, c->L, lin_tile_rows(c));
     return lin_steps_supported(c) && lin_nb(c) == 3 && lin_persist_lds(c) <= 160 * 1024 && sl.passes <= 12 &&
            c->n_cu >= 1 + kLinReduceSets * kLinReduceWgs + 16;
 }
 // streamer workgroups of the persistent launch: the CUs the updater and the reducers leave, tiles dealt evenly
 static int lin_persist_streamers(const vaek_ctx* c) {
-    const int ntiles = (c->B + 255) / 256, smax = c->n_cu - 1 - kLinReduceSets * kLinReduceWgs;
+    const int ntiles = lin_ntiles(c), smax = c->n_cu - 1 - kLinReduceSets * kLinReduceWgs;
     const int per = (ntiles + smax - 1) / smax;
     return (ntiles + per - 1) / per;
 }
 
 struct LinWs { float* partial; double* M; unsigned* cnt; const float** tab; size_t total; };
 static LinWs lin_carve(const vaek_ctx* c, char* base) {
-    const size_t no = lin_no(c), ntiles = (c->B + 255) / 256;
+    const size_t no = lin_no(c), ntiles = lin_ntiles(c);
     const int slots = lin_persist_supported(c) ? kLinMaxPersist : 2;
     LinWs w{};
     size_t off = 0;
@@ -802,7 +823,7 @@ size_t lin_steps_workspace_bytes(const vaek_ctx* c) { return lin_steps_supported
 
 typedef void (*LinKernel)(const LinArgs);
 static int lin_fill_common(const vaek_ctx* c, LinArgs& a, float* params, float* grads, float* m, float* v, int32_t* step_dev, float lr) {
-    a.B = c->B; a.D = c->D; a.L = c->L; a.ntiles = (c->B + 255) / 256;
+    a.B = c->B; a.D = c->D; a.L = c->L; a.T = lin_tile_rows(c); a.ntiles = lin_ntiles(c);
     a.params = params; a.grads = grads; a.m = m; a.v = v; a.step_dev = step_dev; a.lr = lr;
     a.inv_bt = (float)(1.0 / (double)c->Bt); a.eps_cli = c->cfg.eps_cli; a.rows = (float)c->B;
     a.rows_over_bt = (float)((double)c->B / (double)c->Bt); a.off_eps = (int)c->off_eps; a.P = (int)c->P;
@@ -812,7 +833,7 @@ static int lin_fill_common(const vaek_ctx* c, LinArgs& a, float* params, float* 
 
 int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v, int32_t* step_dev, const float* const* xs,
                     const float* const* z1s, const float* const* z2s, int n_steps, float lr, void* ws, hipStream_t st) {
-    const int NB = lin_nb(c), no = lin_no(c), ntiles = (c->B + 255) / 256;
+    const int NB = lin_nb(c), no = lin_no(c), ntiles = lin_ntiles(c);
     const LinWs w = lin_carve(c, static_cast<char*>(ws) + c->ws_lin);
     // the metric's shape with its dimensions at compile time; every other linear model on the run-time instantiations
     const int which = (c->D == 12 && c->L == 20) ? 0 : (NB <= 3 ? 1 : 2);
