@@ -686,8 +686,8 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) { 
             lin_wait_count(a.cnt_stream + n, (unsigned)a.ntiles, a.status, (2u << 28) | ((unsigned)n << 16));
             LIN_NOWQ(r1);
             if (!(a.diag & 1))
-                for (int sub = ro; sub < NO / 32; sub += per_set) {        // 32 outputs at a time
-                    if (sub != ro) __syncthreads();                     // the previous slice's LDS sums have been read
+                for (int sub = ro; sub < NO / 32; sub += per_set) {        // 32 outputs at a time (a 128-output form reading 16 bytes per
+                    if (sub != ro) __syncthreads();                     // lane with sc1 buffer loads measured 8 % SLOWER per step)
                     lin_reduce<true>(a.partial_base + (long long)n * a.ntiles * NO, a.M_base + (long long)n * NO, a.ntiles, lin_smem, sub, NO);
                 }
             lin_wait_vmcnt<0>();                               // every storing wave drains its write-through stores ...
