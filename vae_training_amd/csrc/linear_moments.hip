@@ -50,8 +50,8 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 
 constexpr int LNT = 512, LNW = LNT / 64;          // threads / waves per workgroup, every role
 constexpr int kLinMaxPersist = 64;                // steps per persistent launch (each owns a partial / M slot)
-constexpr int kLinReduceSets = 2;                 // persistent form: reducer sets taking alternate batches
-constexpr int kLinReduceWgs = 12;                 // workgroups per set, each summing NO / 32 / 12 slices of 32 outputs (more resident
+constexpr int kLinReduceSets = 1;                 // persistent form: reducer sets taking alternate batches (one set of 24 beat two of 12)
+constexpr int kLinReduceWgs = 24;                 // workgroups per set, each summing NO / 32 / 24 slices of 32 outputs (more resident
                                                   // workgroups measurably slow the streamers: 48 per set cost 2 us per step)
 
 struct LinArgs {
@@ -63,7 +63,7 @@ struct LinArgs {
     const float* partial_in; double* M_out;                                       // [NBLK * 256]
     const double* M_in;
     // ---- persistent form: n_steps batches, pointer tables in device memory, one slot per batch, arrival counters
-    int persistent, n_steps, diag;
+    int persistent, n_steps, diag, sets;          // sets: reducer sets taking alternate batches
     const float* const* xs; const float* const* z1s; const float* const* z2s;
     float* partial_base; double* M_base;                                          // slot n at + n * ntiles * NO resp. + n * NO
     unsigned* cnt_stream; unsigned* cnt_reduce; unsigned* status;                 // [n_steps], [n_steps], [1]; zeroed before the launch
@@ -173,11 +173,14 @@ __device__ __forceinline__ void lin_issue_tile(const LinArgs& a, const LinSlot& 
     const long long row0 = (long long)tile * a.T;
     auto copy = [&](const float* src, int cols, int bytes, int lds_off) {
         const long long tot = (long long)a.B * cols * 4, base = row0 * cols * 4;
+        // the last 16-byte piece this tile may fetch: the tile's own (the slot's padding up to whole 8 KB passes re-reads it -- a
+        // line this CU has just fetched -- instead of pulling the NEXT tile's rows through another XCD's L2: 10 % of the HBM reads),
+        // and never past the tensor's last whole 16 bytes; what a clamped piece brings lands in LDS nobody reads, in rows that are
+        // zeroed afterwards, or in the tensor's last <= 3 floats, which lin_fix_tile rewrites
+        const long long last = min(tot & ~15ll, base + (long long)a.T * cols * 4) - 16;
         for (int i = 0; i < bytes / 8192; ++i) {
             long long off = base + i * 8192 + t * 16;
-            // a 16-byte piece that would run past the tensor's last whole 16 bytes: a valid, aligned address instead; what it
-            // brings lands in rows that are zeroed afterwards -- or in the tensor's last <= 3 floats, which lin_fix_tile rewrites
-            off = off + 16 <= (tot & ~15ll) ? off : ((tot & ~15ll) - 16);
+            off = off <= last ? off : last;
             lin_glds16(reinterpret_cast<const char*>(src) + off, slot + lds_off + i * 8192 + wave * 1024);
         }
     };
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) { 
     extern __shared__ __attribute__((aligned(16))) char lin_smem[];
     const int b = blockIdx.x, t = threadIdx.x, N = a.n_steps;
     constexpr int NO = NB * (NB + 1) / 2 * 256;
-    const int per_set = a.n_reduce / kLinReduceSets;          // reducer workgroups per set
+    const int per_set = a.n_reduce / a.sets;                  // reducer workgroups per set
     if (b < a.has_update) {
         // ---- the updater: one workgroup, parameters and Adam state in registers / LDS across all N steps -------------------
         LinUpd<NB, DT, LT> u;
@@ -681,7 +684,7 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) { 
         // ---- reducers: set (rb / per_set) takes batches set, set + 2, ... ------------------------------------------------------
         const int rb = b - a.has_update, set = rb / per_set, ro = rb % per_set;
         unsigned long long r0 = 0, r1 = 0, r2 = 0, racc_w = 0, racc_r = 0;
-        for (int n = set; n < N; n += kLinReduceSets) {
+        for (int n = set; n < N; n += a.sets) {
             LIN_NOWQ(r0);
             lin_wait_count(a.cnt_stream + n, (unsigned)a.ntiles, a.status, (2u << 28) | ((unsigned)n << 16));
             LIN_NOWQ(r1);
@@ -861,6 +864,8 @@ int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v
             lin_fill_common(c, a, params, grads, m, v, step_dev, lr);
             a.persistent = 1; a.n_steps = n;
             static const int rwg = getenv("VAEK_LIN_RWG") ? atoi(getenv("VAEK_LIN_RWG")) : kLinReduceWgs;     // diagnostic override
+            static const int sets = getenv("VAEK_LIN_SETS") ? atoi(getenv("VAEK_LIN_SETS")) : kLinReduceSets;    // diagnostic override
+            a.sets = sets;
             a.has_update = 1; a.n_reduce = kLinReduceSets * std::min(rwg, no / 32); a.n_stream = lin_persist_streamers(c);
             static const int proles = getenv("VAEK_LIN_ROLES") ? atoi(getenv("VAEK_LIN_ROLES")) : 7;    // diagnostic (tools/lin_roles.sh)
             a.diag = getenv("VAEK_LIN_DIAG") ? atoi(getenv("VAEK_LIN_DIAG")) : 0;
