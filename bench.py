@@ -387,6 +387,42 @@ def main():
     if exch is not None and exch.in_library:
         assert not exch.timed_out(), "p2p gradient exchange gave up waiting for a peer"
 
+    # ---- A/B (never `value`): the same workload through the drop-in per-sample step, vaek_train_step (two launches per step:
+    # the fused forward/backward chain + finalize/Adam), captured and timed the same way -- what `value` was in round 1
+    per_sample = None
+    if use_pipe and world == 1:
+        gs2 = max(2, min(gsteps if gsteps > 0 else 20, 200))
+        p2, g2, m2, v2 = params.clone(), eng.new_flat(eng.grad_len), m.clone(), v.clone()
+        s2 = step_dev.clone()
+
+        def ps_steps(n):
+            for k in range(n):
+                x, z1, z2 = batches[k % len(batches)]
+                eng.train_step(p2, g2, m2, v2, s2, x, z1, z2, lr)
+        ps_steps(3)
+        torch.cuda.synchronize()
+        side2 = torch.cuda.Stream()
+        side2.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side2):
+            graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph2, stream=side2):
+                ps_steps(gs2)
+        torch.cuda.current_stream().wait_stream(side2)
+        graph2.replay()
+        if mall_sweep is not None:
+            mall_sweep.fill_(1.0)
+            ps_steps(4)
+        torch.cuda.synchronize()
+        reps = max(1, min(args.steps, 400) // gs2)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            graph2.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        per_sample = {"entry_point": "vaek_train_step (per-sample forward/backward chain + finalize: two launches per step)",
+                      "samples_per_s": B_local * reps * gs2 / dt, "us_per_step": dt / (reps * gs2) * 1e6, "steps": reps * gs2,
+                      "launch": f"hipGraph x{gs2} steps"}
+
     # ---- roofline leg: the same steps again with every library launch bracketed by its own begin/end timestamps ----
     roofline = None
     if not args.no_roofline:
@@ -517,7 +553,7 @@ def main():
                        "parallelism": f"dp{world}", "grad_exchange": (exch.mode if exch else "none"),
                        "launch": (f"hipGraph x{gsteps} steps" if graph is not None else "eager"), "input_batches": nbuf,
                        "final_loss": loss},
-            "roofline": roofline, "cpu_baseline": cpu, "fresh_inputs_each_step": fresh,
+            "roofline": roofline, "cpu_baseline": cpu, "per_sample_path": per_sample, "fresh_inputs_each_step": fresh,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:
