@@ -443,8 +443,11 @@ def main():
                 # layer-by-layer path: the Dense kernels run once per layer; the step's flops are priced against the time
                 # of all Dense launches of a step
                 alg = B_local * flops_per_sample(w)
-                kernel_s = sum(r["total_ms"] for k, r in rep.items() if k.startswith("gemm")) / rsteps * 1e-3
-                kernel_name = "all Dense (gemm_*) launches of a step"
+                if eng.fused:       # whole-network kernel (one-hidden-layer MLPs): every flop of the step is in that one launch
+                    kernel_s, kernel_name = dom_avg_s, dom
+                else:
+                    kernel_s = sum(r["total_ms"] for k, r in rep.items() if k.startswith("gemm")) / rsteps * 1e-3
+                    kernel_name = "all Dense (gemm_*) launches of a step"
                 peak, unit, bound, scale = (2500.0 if args.dtype == "bf16" else 157.3), "TFLOP/s", "mfma", 1e12
                 alg_step = alg
             else:

@@ -1,0 +1,401 @@
+// Whole-network train-step kernel for VAEs whose encoder and decoder(s) have ONE hidden layer of at most 256 units
+// (BASELINE config 2: sigmoid dataset, 7 -> 256 -> 6, two decoders 6 -> 256 -> 7): VAE.apply forward (networks.py:61-84 --
+// encoder Dense/relu/Dense networks.py:26-44, reparameterisation :73-74, decoder(s) :75-80, decoder noise :81-83), the ELBO
+// (:94-98) and the whole backward pass (what jax.value_and_grad returns at :99) in ONE launch; x, z1, z2 are read once,
+// no activation ever reaches HBM, and each workgroup leaves one partial row of the flat gradient (+ the three scalar
+// sums) for fused_finalize_kernel (fused_small.hip: fixed-order sum, closed-form KL terms, loss, optional P2P exchange,
+// Adam) -- the same two-launch step as the linear models' fused path.  The layer-by-layer path took ~20 launches for
+// this model (172 us per step at B = 8 192, 2 % of the f32 matrix peak).
+//
+// One workgroup = 256 threads = 4 waves, a tile of 32 samples at a time (tiles tile, tile + grid, ...; the gradient
+// accumulates in registers across them).  Thread j IS hidden unit j of all three networks:
+//   * its columns / rows of the six weight matrices live in its registers (loaded once, coalesced);
+//   * the layers with a small inner dimension (x -> hidden, samples -> hidden, and every backward product through them)
+//     are per-thread loops over the 32 samples with the small operand broadcast from LDS;
+//   * the three hidden activations live in LDS as [unit][sample] (row stride 36 floats), later overwritten in place by
+//     their gradients;
+//   * the layers that REDUCE over the hidden units (hidden -> mu, hidden -> x_hat, d hidden -> d samples) run on
+//     v_mfma_f32_16x16x4_f32 (exact f32) with features on the rows and samples on the columns: A = the thread-held
+//     weights staged as [unit][feature] in a small LDS scratch, B = the activation image; wave w takes sample block
+//     w & 1 and half (w >> 1) of the units, the two halves meet through LDS.
+// Every sum over samples or units has a fixed order: bitwise run-to-run repeatable, like the rest of the library.
+#include "vaek_internal.h"
+
+namespace vaek {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int M1_TS = 32;            // samples per tile
+constexpr int M1_NT = 256;           // threads = hidden units covered
+constexpr int M1_HS = 36;            // row stride (floats) of the [unit][sample] activation images
+constexpr int M1_FS = 16;            // row stride of the [sample][feature] images (features padded to 16)
+
+struct Mlp1Args {
+    const float* x; const float* z1; const float* z2; const float* params; float* partials;
+    int pstride, B, D, L, He, Hd, ntiles;
+    float inv_bt, eps_cli;
+    int off_e1w, off_e1b, off_e2w, off_e2b, off_d1w, off_d1b, off_d2w, off_d2b, off_s1w, off_s1b, off_s2w, off_s2b;
+    int off_epsp, off_eps, P;
+    int32_t* step_dev;                       // the Adam step counter: advanced here, read by the finalize launch behind
+};
+
+struct Mlp1Lds {
+    float X[M1_TS][M1_FS], Z1[M1_TS][M1_FS], Z2[M1_TS][M1_FS];
+    float MU[M1_TS][M1_FS], SMP[M1_TS][M1_FS], XL[M1_TS][M1_FS], XS[M1_TS][M1_FS];
+    float DY[M1_TS][M1_FS], DYS[M1_TS][M1_FS], DS[M1_TS][M1_FS], DMU[M1_TS][M1_FS];
+    float WS[M1_NT][M1_FS];                  // MFMA A operand of the current pass: [unit][feature]
+    float TMP[2][64][4];                     // the upper unit-half's accumulators on their way to the lower half's waves
+    float RED[4][4];                         // per-wave scalar partials
+    float HE[M1_NT][M1_HS], HD[M1_NT][M1_HS], HSg[M1_NT][M1_HS];
+};
+
+// out^T[feature][sample] (+)= sum_units W[unit][feature] * Himg[unit][sample] for this wave's sample block and unit half;
+// the lower half's waves return the full sum for (sample = 16 b + lane % 16, features 4 g .. 4 g + 3), the others zeros.
+// Callers put a barrier between staging WS / finishing Himg and this, and before re-staging WS.
+__device__ __forceinline__ f32x4 m1_reduce_units(Mlp1Lds& s, const float (*Himg)[M1_HS], f32x4 acc, int wave, int lane) {
+    const int b = wave & 1, kh = wave >> 1, n = lane & 15, kq = lane >> 4;
+#pragma unroll 8
+    for (int q = 32 * kh; q < 32 * kh + 32; ++q) {
+        const int u = 4 * q + kq;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(s.WS[u][n], Himg[u][16 * b + n], acc, 0, 0, 0);
+    }
+    return acc;
+}
+__device__ __forceinline__ f32x4 m1_meet_halves(Mlp1Lds& s, f32x4 acc, int wave, int lane) {
+    const int b = wave & 1, kh = wave >> 1;
+    if (kh == 1) *reinterpret_cast<f32x4*>(s.TMP[b][lane]) = acc;
+    __syncthreads();
+    if (kh == 0) acc += *reinterpret_cast<const f32x4*>(s.TMP[b][lane]);
+    return acc;
+}
+
+template <int DP, int LP, bool SIG>
+__global__ __launch_bounds__(M1_NT) void mlp1_fused_kernel(const Mlp1Args a) {
+    extern __shared__ __attribute__((aligned(16))) char m1_smem[];
+    Mlp1Lds& s = *reinterpret_cast<Mlp1Lds*>(m1_smem);
+    const int j = threadIdx.x, lane = j & 63, wave = __builtin_amdgcn_readfirstlane(j >> 6);
+    const int D = a.D, L = a.L;
+    const float* const P = a.params;
+    const bool je = j < a.He, jd = j < a.Hd;
+    if (blockIdx.x == 0 && j == 0 && a.step_dev) a.step_dev[0] += 1;
+
+    // ---- this unit's weights (zero for units / features that do not exist: they then contribute nothing anywhere)
+    float we1[DP], we2[LP], wd1[LP], wd2[DP], ws1[LP], ws2[DP];
+    const float be1 = je ? P[a.off_e1b + j] : 0.f, bd1 = jd ? P[a.off_d1b + j] : 0.f, bs1 = (SIG && jd) ? P[a.off_s1b + j] : 0.f;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+        we1[k] = (je && k < D) ? P[a.off_e1w + k * a.He + j] : 0.f;
+        wd2[k] = (jd && k < D) ? P[a.off_d2w + j * D + k] : 0.f;
+        ws2[k] = (SIG && jd && k < D) ? P[a.off_s2w + j * D + k] : 0.f;
+    }
+#pragma unroll
+    for (int l = 0; l < LP; ++l) {
+        we2[l] = (je && l < L) ? P[a.off_e2w + j * L + l] : 0.f;
+        wd1[l] = (jd && l < L) ? P[a.off_d1w + l * a.Hd + j] : 0.f;
+        ws1[l] = (SIG && jd && l < L) ? P[a.off_s1w + l * a.Hd + j] : 0.f;
+    }
+    // small vectors every epilogue lane needs: biases of the reducing layers, e^{lv/2}, for features 4 g .. 4 g + 3
+    const int f0 = 4 * (lane >> 4);
+    float be2[4], bd2[4], bs2[4], shl[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int f = f0 + r;
+        be2[r] = f < L ? P[a.off_e2b + f] : 0.f;
+        bd2[r] = f < D ? P[a.off_d2b + f] : 0.f;
+        bs2[r] = (SIG && f < D) ? P[a.off_s2b + f] : 0.f;
+        shl[r] = f < L ? expf(0.5f * P[a.off_epsp + f]) : 0.f;
+    }
+    const float eps = a.off_eps >= 0 ? P[a.off_eps] * a.eps_cli : a.eps_cli;
+    const float sigma = expf(0.5f * eps), inv_var = expf(-eps);
+
+    // ---- gradient accumulators of this unit (registers, across all tiles of this workgroup)
+    float g_we1[DP], g_we2[LP], g_wd1[LP], g_wd2[DP], g_ws1[LP], g_ws2[DP];
+    float g_be1 = 0.f, g_bd1 = 0.f, g_bs1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) { g_we1[k] = 0.f; g_wd2[k] = 0.f; g_ws2[k] = 0.f; }
+#pragma unroll
+    for (int l = 0; l < LP; ++l) { g_we2[l] = 0.f; g_wd1[l] = 0.f; g_ws1[l] = 0.f; }
+    // small outputs: thread t < 16 owns feature t of d be2 / d bd2 / d bs2 / the epsilon_p partial; scalar sums per thread
+    float g_be2 = 0.f, g_bd2 = 0.f, g_bs2 = 0.f, g_epsp = 0.f;
+    float p_mse = 0.f, p_musq = 0.f, p_deps = 0.f;
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int row0 = tile * M1_TS, valid = min(M1_TS, a.B - row0);
+        __syncthreads();                                   // the previous tile's images are no longer read
+        // ---- inputs, zero-padded to [32][16]
+        for (int e = j; e < M1_TS * M1_FS; e += M1_NT) {
+            const int r = e / M1_FS, c = e % M1_FS;
+            const bool in = r < valid;
+            const long long row = row0 + (in ? r : 0);
+            (&s.X[0][0])[e] = (in && c < D) ? a.x[row * D + c] : 0.f;
+            (&s.Z1[0][0])[e] = (in && c < L) ? a.z1[row * L + c] : 0.f;
+            (&s.Z2[0][0])[e] = (in && c < D) ? a.z2[row * D + c] : 0.f;
+        }
+        __syncthreads();
+        // ---- encoder layer 1: HE[j][s] = relu(x[s] . We1[:, j] + be1[j])
+#pragma unroll 2
+        for (int s4 = 0; s4 < M1_TS; s4 += 4) {
+            f32x4 h;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float acc = be1;
+#pragma unroll
+                for (int k = 0; k < DP; ++k) acc = fmaf(s.X[s4 + u][k], we1[k], acc);
+                h[u] = fmaxf(acc, 0.f);
+            }
+            *reinterpret_cast<f32x4*>(&s.HE[j][s4]) = h;
+        }
+#pragma unroll
+        for (int l = 0; l < M1_FS; ++l) s.WS[j][l] = l < LP ? we2[l < LP ? l : 0] : 0.f;
+        __syncthreads();
+        // ---- mu = HE^T We2 + be2; samples = mu + e^{lv/2} z1
+        {
+            f32x4 acc = m1_reduce_units(s, s.HE, f32x4{0.f, 0.f, 0.f, 0.f}, wave, lane);
+            acc = m1_meet_halves(s, acc, wave, lane);
+            if ((wave >> 1) == 0) {
+                const int smp = 16 * (wave & 1) + (lane & 15);
+                const f32x4 z = *reinterpret_cast<const f32x4*>(&s.Z1[smp][f0]);
+                f32x4 mu, sm;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { mu[r] = acc[r] + be2[r]; sm[r] = fmaf(shl[r], z[r], mu[r]); }
+                *reinterpret_cast<f32x4*>(&s.MU[smp][f0]) = mu;
+                *reinterpret_cast<f32x4*>(&s.SMP[smp][f0]) = sm;
+                if (smp < valid) p_musq += (mu[0] * mu[0] + mu[1] * mu[1]) + (mu[2] * mu[2] + mu[3] * mu[3]);
+            }
+        }
+        __syncthreads();
+        // ---- decoder(s) layer 1
+#pragma unroll 2
+        for (int s4 = 0; s4 < M1_TS; s4 += 4) {
+            f32x4 h, hs;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float acc = bd1, accs = bs1;
+#pragma unroll
+                for (int l = 0; l < LP; ++l) {
+                    const float sv = s.SMP[s4 + u][l];
+                    acc = fmaf(sv, wd1[l], acc);
+                    if (SIG) accs = fmaf(sv, ws1[l], accs);
+                }
+                h[u] = fmaxf(acc, 0.f); hs[u] = fmaxf(accs, 0.f);
+            }
+            *reinterpret_cast<f32x4*>(&s.HD[j][s4]) = h;
+            if (SIG) *reinterpret_cast<f32x4*>(&s.HSg[j][s4]) = hs;
+        }
+#pragma unroll
+        for (int k = 0; k < M1_FS; ++k) s.WS[j][k] = k < DP ? wd2[k < DP ? k : 0] : 0.f;
+        __syncthreads();
+        // ---- x_hat (linear decoder) = HD^T Wd2 + bd2
+        {
+            f32x4 acc = m1_reduce_units(s, s.HD, f32x4{0.f, 0.f, 0.f, 0.f}, wave, lane);
+            acc = m1_meet_halves(s, acc, wave, lane);
+            if ((wave >> 1) == 0) {
+                const int smp = 16 * (wave & 1) + (lane & 15);
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[r] + bd2[r];
+                *reinterpret_cast<f32x4*>(&s.XL[smp][f0]) = o;
+            }
+        }
+        if (SIG) {
+            __syncthreads();                               // every wave is done with WS
+#pragma unroll
+            for (int k = 0; k < M1_FS; ++k) s.WS[j][k] = k < DP ? ws2[k < DP ? k : 0] : 0.f;
+            __syncthreads();
+            f32x4 acc = m1_reduce_units(s, s.HSg, f32x4{0.f, 0.f, 0.f, 0.f}, wave, lane);
+            acc = m1_meet_halves(s, acc, wave, lane);
+            if ((wave >> 1) == 0) {
+                const int smp = 16 * (wave & 1) + (lane & 15);
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = 1.f / (1.f + expf(-(acc[r] + bs2[r])));
+                *reinterpret_cast<f32x4*>(&s.XS[smp][f0]) = o;
+            }
+        }
+        __syncthreads();
+        // ---- ELBO, elementwise over [32][16]: decoder noise, residual, dL/dx_hat, the sigmoid head's gradient, scalar sums
+        for (int e = j; e < M1_TS * M1_FS; e += M1_NT) {
+            const int r = e / M1_FS, c = e % M1_FS;
+            const bool in = r < valid && c < D;
+            const float sg = SIG ? (&s.XS[0][0])[e] : 0.f;
+            const float z2v = (&s.Z2[0][0])[e];
+            const float res = (&s.XL[0][0])[e] + sg + z2v * sigma - (&s.X[0][0])[e];
+            const float dy = in ? res * inv_var * a.inv_bt : 0.f;
+            (&s.DY[0][0])[e] = dy;
+            if (SIG) (&s.DYS[0][0])[e] = dy * sg * (1.f - sg);
+            if (in) {
+                const float q = 0.5f * res * res * inv_var;
+                p_mse += q;
+                p_deps += -q + 0.5f * sigma * z2v * res * inv_var;
+            }
+        }
+        __syncthreads();
+        // ---- decoder(s) backward through layer 2 and the relu; the activation images become gradient images
+#pragma unroll 2
+        for (int s4 = 0; s4 < M1_TS; s4 += 4) {
+            const f32x4 h = *reinterpret_cast<const f32x4*>(&s.HD[j][s4]);
+            f32x4 hs = {0.f, 0.f, 0.f, 0.f}, dh, dhs;
+            if (SIG) hs = *reinterpret_cast<const f32x4*>(&s.HSg[j][s4]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < DP; ++k) {
+                    const float dyv = s.DY[s4 + u][k];
+                    g_wd2[k] = fmaf(h[u], dyv, g_wd2[k]);
+                    d1 = fmaf(dyv, wd2[k], d1);
+                    if (SIG) {
+                        const float dsv = s.DYS[s4 + u][k];
+                        g_ws2[k] = fmaf(hs[u], dsv, g_ws2[k]);
+                        d2 = fmaf(dsv, ws2[k], d2);
+                    }
+                }
+                d1 = h[u] > 0.f ? d1 : 0.f;
+                d2 = hs[u] > 0.f ? d2 : 0.f;
+                g_bd1 += d1; g_bs1 += d2;
+#pragma unroll
+                for (int l = 0; l < LP; ++l) {
+                    const float sv = s.SMP[s4 + u][l];
+                    g_wd1[l] = fmaf(sv, d1, g_wd1[l]);
+                    if (SIG) g_ws1[l] = fmaf(sv, d2, g_ws1[l]);
+                }
+                dh[u] = d1; dhs[u] = d2;
+            }
+            *reinterpret_cast<f32x4*>(&s.HD[j][s4]) = dh;
+            if (SIG) *reinterpret_cast<f32x4*>(&s.HSg[j][s4]) = dhs;
+        }
+#pragma unroll
+        for (int l = 0; l < M1_FS; ++l) s.WS[j][l] = l < LP ? wd1[l < LP ? l : 0] : 0.f;
+        __syncthreads();
+        // ---- d samples = dHD^T Wd1^T (+ dHS^T Ws1^T); d mu = d samples + mu / Bt
+        {
+            f32x4 acc = m1_reduce_units(s, s.HD, f32x4{0.f, 0.f, 0.f, 0.f}, wave, lane);
+            if (SIG) {
+                __syncthreads();
+#pragma unroll
+                for (int l = 0; l < M1_FS; ++l) s.WS[j][l] = l < LP ? ws1[l < LP ? l : 0] : 0.f;
+                __syncthreads();
+                acc = m1_reduce_units(s, s.HSg, acc, wave, lane);
+            }
+            acc = m1_meet_halves(s, acc, wave, lane);
+            if ((wave >> 1) == 0) {
+                const int smp = 16 * (wave & 1) + (lane & 15);
+                const f32x4 mu = *reinterpret_cast<const f32x4*>(&s.MU[smp][f0]);
+                f32x4 dmu;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dmu[r] = smp < valid ? fmaf(mu[r], a.inv_bt, acc[r]) : 0.f;
+                *reinterpret_cast<f32x4*>(&s.DS[smp][f0]) = acc;
+                *reinterpret_cast<f32x4*>(&s.DMU[smp][f0]) = dmu;
+            }
+        }
+        __syncthreads();
+        // ---- encoder backward
+#pragma unroll 2
+        for (int s4 = 0; s4 < M1_TS; s4 += 4) {
+            const f32x4 h = *reinterpret_cast<const f32x4*>(&s.HE[j][s4]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float d1 = 0.f;
+#pragma unroll
+                for (int l = 0; l < LP; ++l) {
+                    const float dm = s.DMU[s4 + u][l];
+                    g_we2[l] = fmaf(h[u], dm, g_we2[l]);
+                    d1 = fmaf(dm, we2[l], d1);
+                }
+                d1 = h[u] > 0.f ? d1 : 0.f;
+                g_be1 += d1;
+#pragma unroll
+                for (int k = 0; k < DP; ++k) g_we1[k] = fmaf(s.X[s4 + u][k], d1, g_we1[k]);
+            }
+        }
+        // ---- the small vectors: thread t < 16 sums feature t over the samples
+        if (j < M1_FS) {
+            for (int r = 0; r < M1_TS; ++r) {
+                g_be2 += s.DMU[r][j]; g_bd2 += s.DY[r][j];
+                if (SIG) g_bs2 += s.DYS[r][j];
+                g_epsp = fmaf(s.DS[r][j], s.Z1[r][j], g_epsp);
+            }
+        }
+    }
+
+    // ---- this workgroup's partial row
+    float* const row = a.partials + (long long)blockIdx.x * a.pstride;
+    if (je) {
+        row[a.off_e1b + j] = g_be1;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) if (k < D) row[a.off_e1w + k * a.He + j] = g_we1[k];
+#pragma unroll
+        for (int l = 0; l < LP; ++l) if (l < L) row[a.off_e2w + j * L + l] = g_we2[l];
+    }
+    if (jd) {
+        row[a.off_d1b + j] = g_bd1;
+#pragma unroll
+        for (int l = 0; l < LP; ++l) if (l < L) row[a.off_d1w + l * a.Hd + j] = g_wd1[l];
+#pragma unroll
+        for (int k = 0; k < DP; ++k) if (k < D) row[a.off_d2w + j * D + k] = g_wd2[k];
+        if (SIG) {
+            row[a.off_s1b + j] = g_bs1;
+#pragma unroll
+            for (int l = 0; l < LP; ++l) if (l < L) row[a.off_s1w + l * a.Hd + j] = g_ws1[l];
+#pragma unroll
+            for (int k = 0; k < DP; ++k) if (k < D) row[a.off_s2w + j * D + k] = g_ws2[k];
+        }
+    }
+    if (j < L) { row[a.off_e2b + j] = g_be2; row[a.off_epsp + j] = g_epsp; }
+    if (j < D) { row[a.off_d2b + j] = g_bd2; if (SIG) row[a.off_s2b + j] = g_bs2; }
+    // the three scalar sums: lanes by xor-shuffle, the four waves in order
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        p_mse += __shfl_xor(p_mse, o, 64); p_musq += __shfl_xor(p_musq, o, 64); p_deps += __shfl_xor(p_deps, o, 64);
+    }
+    __syncthreads();
+    if (lane == 0) { s.RED[wave][0] = p_mse; s.RED[wave][1] = p_musq; s.RED[wave][2] = p_deps; }
+    __syncthreads();
+    if (j < 3) row[a.P + j] = (s.RED[0][j] + s.RED[1][j]) + (s.RED[2][j] + s.RED[3][j]);
+    if (j == 3) { row[a.P + 3] = 0.f; if (a.off_eps >= 0) row[a.off_eps] = 0.f; }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------------
+bool mlp1_supported(const vaek_ctx* c) {
+    return c->cfg.n_enc_hidden == 1 && c->cfg.n_dec_hidden == 1 && c->cfg.dtype == VAEK_F32 && c->D <= 16 && c->L <= 16 &&
+           c->cfg.enc_hidden[0] <= M1_NT && c->cfg.dec_hidden[0] <= M1_NT && c->cfg.enc_hidden[0] >= 1 && c->cfg.dec_hidden[0] >= 1;
+}
+int mlp1_grid(const vaek_ctx* c) {
+    const int ntiles = (c->B + M1_TS - 1) / M1_TS;
+    return std::max(1, std::min(ntiles, c->n_cu));          // one workgroup per CU (its LDS image is ~135 KB)
+}
+
+typedef void (*Mlp1Kernel)(const Mlp1Args);
+int mlp1_launch(vaek_ctx* c, const float* params, const float* x, const float* z1, const float* z2, float* partials, int pstride,
+                int32_t* step_dev, hipStream_t st) {
+    Mlp1Args a{};
+    a.step_dev = step_dev;
+    a.x = x; a.z1 = z1; a.z2 = z2; a.params = params; a.partials = partials; a.pstride = pstride;
+    a.B = c->B; a.D = c->D; a.L = c->L; a.He = c->cfg.enc_hidden[0]; a.Hd = c->cfg.dec_hidden[0];
+    a.ntiles = (c->B + M1_TS - 1) / M1_TS;
+    a.inv_bt = (float)(1.0 / (double)c->Bt); a.eps_cli = c->cfg.eps_cli;
+    const int D = c->D, L = c->L, He = a.He, Hd = a.Hd;
+    int off = 0;
+    a.off_e1w = off; off += D * He; a.off_e1b = off; off += He; a.off_e2w = off; off += He * L; a.off_e2b = off; off += L;
+    a.off_d1w = off; off += L * Hd; a.off_d1b = off; off += Hd; a.off_d2w = off; off += Hd * D; a.off_d2b = off; off += D;
+    if (c->cfg.sigmoid_decoder) {
+        a.off_s1w = off; off += L * Hd; a.off_s1b = off; off += Hd; a.off_s2w = off; off += Hd * D; a.off_s2b = off; off += D;
+    }
+    if (off != (int)c->off_epsp) { set_error("mlp1: parameter layout mismatch"); return VAEK_ERR_INVALID; }
+    a.off_epsp = (int)c->off_epsp; a.off_eps = (int)c->off_eps; a.P = (int)c->P;
+    const bool big = D > 8 || L > 8, sig = c->cfg.sigmoid_decoder != 0;
+    const Mlp1Kernel fn = big ? (sig ? mlp1_fused_kernel<16, 16, true> : mlp1_fused_kernel<16, 16, false>)
+                              : (sig ? mlp1_fused_kernel<8, 8, true> : mlp1_fused_kernel<8, 8, false>);
+    static thread_local bool attr_set[4] = {};
+    const int vi = (big ? 2 : 0) + (sig ? 1 : 0);
+    if (!attr_set[vi]) {
+        VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Mlp1Lds)));
+        attr_set[vi] = true;
+    }
+    ProfScope ps("fused_mlp1_fwd_bwd", st);
+    launch_k(ps, fn, dim3((unsigned)mlp1_grid(c)), dim3(M1_NT), sizeof(Mlp1Lds), st, a);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+}  // namespace vaek

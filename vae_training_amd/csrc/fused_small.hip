@@ -558,11 +558,11 @@ static int fused_grid(const vaek_ctx* c, const FusedVariant* v) {
 }
 static int fused_pstride(const vaek_ctx* c) { return (int)((c->P + kExtra + 63) / 64 * 64); }
 
-bool fused_supported(const vaek_ctx* c) { return pick_variant(c) != nullptr; }
+bool fused_supported(const vaek_ctx* c) { return pick_variant(c) != nullptr || mlp1_supported(c); }
 
 size_t fused_workspace_bytes(const vaek_ctx* c) {
     const FusedVariant* v = pick_variant(c);
-    if (!v) return 0;
+    if (!v) return mlp1_supported(c) ? (size_t)mlp1_grid(c) * fused_pstride(c) * sizeof(float) : 0;
     return (size_t)fused_grid(c, v) * fused_pstride(c) * sizeof(float);
 }
 
@@ -570,19 +570,22 @@ int fused_train_step(vaek_ctx* c, float* params, float* grads, float* m, float* 
                      const float* x, const float* z1, const float* z2, float lr, bool apply_adam, bool exchange,
                      void* ws, hipStream_t st, const BatchArgs* gen) {
     const FusedVariant* var = pick_variant(c);
-    if (!var) { set_error("fused path not available for this configuration"); return VAEK_ERR_INVALID; }
+    const bool mlp1 = !var && mlp1_supported(c);        // one-hidden-layer MLPs: fused_mlp1.hip writes the partial rows
+    if (!var && !mlp1) { set_error("fused path not available for this configuration"); return VAEK_ERR_INVALID; }
     static thread_local const void* lds_set[sizeof(kVariants) / sizeof(kVariants[0])] = {};
-    const size_t vi = var - kVariants;
-    if (var->lds_bytes > 64 * 1024 && lds_set[vi] == nullptr) {
-        VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)var->fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)var->lds_bytes));
-        lds_set[vi] = (const void*)var->fn;
+    if (var) {
+        const size_t vi = var - kVariants;
+        if (var->lds_bytes > 64 * 1024 && lds_set[vi] == nullptr) {
+            VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)var->fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)var->lds_bytes));
+            lds_set[vi] = (const void*)var->fn;
+        }
     }
     float* partials = reinterpret_cast<float*>(static_cast<char*>(ws) + c->ws_fused);
-    const int grid = fused_grid(c, var), pstride = fused_pstride(c);
+    const int grid = mlp1 ? mlp1_grid(c) : fused_grid(c, var), pstride = fused_pstride(c);
     FusedArgs a{};
     a.x = x; a.z1 = z1; a.z2 = z2; a.partials = partials; a.pstride = pstride;
-    a.B = c->B; a.D = c->D; a.L = c->L; a.ntiles = (c->B + fused_tile(c, var) - 1) / fused_tile(c, var);
+    a.B = c->B; a.D = c->D; a.L = c->L; a.ntiles = mlp1 ? 0 : (c->B + fused_tile(c, var) - 1) / fused_tile(c, var);
     a.inv_bt = (float)(1.0 / (double)c->Bt); a.eps_cli = c->cfg.eps_cli;
     const int D = c->D, L = c->L;
     a.off_be = D * L; a.off_wd = a.off_be + L; a.off_bd = a.off_wd + L * D;
@@ -590,7 +593,10 @@ int fused_train_step(vaek_ctx* c, float* params, float* grads, float* m, float* 
     a.off_epsp = (int)c->off_epsp; a.off_eps = (int)c->off_eps; a.P = (int)c->P;
     a.step_dev = step_dev;
     a.stamps = c->dbg_stamps;
-    if (use_mfma(c) && grid == 1 && apply_adam && !exchange && c->cfg.world == 1) {
+    if (mlp1) {
+        const int rc = mlp1_launch(c, params, x, z1, z2, partials, pstride, step_dev, st);
+        if (rc) return rc;
+    } else if (use_mfma(c) && grid == 1 && apply_adam && !exchange && c->cfg.world == 1) {
         // the whole batch is one workgroup's tile: ONE launch (fused_mfma.hip, single-launch step); with a batch to draw,
         // the generator's work items are workgroups 1.. of the same launch
         a.single = 1;
@@ -601,7 +607,8 @@ int fused_train_step(vaek_ctx* c, float* params, float* grads, float* m, float* 
         if (gen) { a.has_gen = 1; a.gen = *gen; launch_grid += (int)((make_batch_item_count(*gen) + 255) / 256); }
         return fused_mfma_launch(c, params, &a, launch_grid, st);
     }
-    if (use_mfma(c)) {
+    if (mlp1) {
+    } else if (use_mfma(c)) {
         int rc = fused_mfma_launch(c, params, &a, grid, st);
         if (rc) return rc;
     } else {

@@ -646,7 +646,7 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) { 
 #pragma unroll
         for (int k = 0; k < LKOUT; ++k) g[k] = 0.f;
         LIN_STAMP(10);
-        unsigned long long tw0 = 0, tw1 = 0, twait = 0, twait_max = 0;
+        [[maybe_unused]] unsigned long long tw0 = 0, tw1 = 0, twait = 0, twait_max = 0;
         double mreg[LinUpd<NB, DT, LT>::MPT];
         bool pre_ok = false;                                   // (uniform) mreg already holds this batch's M
         for (int n = 0; n < N; ++n) {
@@ -677,13 +677,13 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) { 
             u.step(a, tstep, g);
             __syncthreads();                                   // everybody is done reading the LDS copies before they are refreshed
             LIN_STAMP(7);
-            { unsigned long long te = 0; LIN_NOW(te); LIN_PUT(64 + n, te); }
+            { [[maybe_unused]] unsigned long long te = 0; LIN_NOW(te); LIN_PUT(64 + n, te); }
         }
         u.store_state(a, g, tstep);
     } else if (b < a.has_update + a.n_reduce) {
         // ---- reducers: set (rb / per_set) takes batches set, set + 2, ... ------------------------------------------------------
         const int rb = b - a.has_update, set = rb / per_set, ro = rb % per_set;
-        unsigned long long r0 = 0, r1 = 0, r2 = 0, racc_w = 0, racc_r = 0;
+        [[maybe_unused]] unsigned long long r0 = 0, r1 = 0, r2 = 0, racc_w = 0, racc_r = 0;
         for (int n = set; n < N; n += a.sets) {
             LIN_NOWQ(r0);
             lin_wait_count(a.cnt_stream + n, (unsigned)a.ntiles, a.status, (2u << 28) | ((unsigned)n << 16));
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) { 
             racc_w += r1 - r0; racc_r += r2 - r1;
             if (rb == 5) { LIN_PUT(40, racc_w); LIN_PUT(41, racc_r); }
             if (t == 0) __hip_atomic_fetch_add(a.cnt_reduce + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            { unsigned long long te = 0; LIN_NOW(te); LIN_PUTMAX(128 + n, te); }
+            { [[maybe_unused]] unsigned long long te = 0; LIN_NOW(te); LIN_PUTMAX(128 + n, te); }
         }
     } else {
         // ---- streamers: workgroup sid takes tiles sid, sid + S, ... of every batch, in batch order, through a ring of two LDS
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) { 
             lin_issue_tile(a, sl, tab[n], tab[kLinMaxPersist + n], tab[2 * kLinMaxPersist + n], item_tile(i), lin_smem + (i & 1) * stride, t, wave);
         };
         if (items > 0) issue(0);
-        unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, sacc_i = 0, sacc_l = 0, sacc_f = 0, sacc_m = 0;
+        [[maybe_unused]] unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, sacc_i = 0, sacc_l = 0, sacc_f = 0, sacc_m = 0;
         for (int i = 0; i < items; ++i) {
             // (the slot item i + 1 lands in was released by the barrier that closed iteration i - 1)
             LIN_NOWQ(s0);

@@ -290,6 +290,10 @@ int make_batch_args(vaek_ctx* ctx, int32_t kind, const float* A, int32_t dd, int
 int make_batch_launch(vaek_ctx* ctx, const BatchArgs& a, hipStream_t st);
 
 // ---- fused_small.hip ----------------------------------------------------------------------
+bool mlp1_supported(const vaek_ctx* c);          // fused_mlp1.hip: whole-network kernel for one-hidden-layer MLPs (<= 256 units)
+int mlp1_grid(const vaek_ctx* c);
+int mlp1_launch(vaek_ctx* c, const float* params, const float* x, const float* z1, const float* z2, float* partials, int pstride,
+                int32_t* step_dev, hipStream_t st);
 bool fused_supported(const vaek_ctx* c);
 size_t fused_workspace_bytes(const vaek_ctx* c);
 // gen != nullptr: the finalize launch carries extra blocks that draw the NEXT step's batch (vaek_train_step_gen)
