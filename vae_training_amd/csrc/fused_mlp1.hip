@@ -37,7 +37,21 @@ struct Mlp1Args {
     int off_e1w, off_e1b, off_e2w, off_e2b, off_d1w, off_d1b, off_d2w, off_d2b, off_s1w, off_s1b, off_s2w, off_s2b;
     int off_epsp, off_eps, P;
     int32_t* step_dev;                       // the Adam step counter: advanced here, read by the finalize launch behind
+    unsigned long long* stamps;              // -DVAEK_M1_STAMPS builds (tools/m1_stamps.sh): s_memrealtime at the phase boundaries
 };
+
+#ifdef VAEK_M1_STAMPS
+#define M1_STAMP(i)                                                                                          \
+    do {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        unsigned long long _t;                                                                               \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); \
+        if (a.stamps && blockIdx.x == 7 && threadIdx.x == 0) a.stamps[i] = _t;                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    } while (0)
+#else
+#define M1_STAMP(i) do {} while (0)
+#endif
 
 struct Mlp1Lds {
     float X[M1_TS][M1_FS], Z1[M1_TS][M1_FS], Z2[M1_TS][M1_FS];
@@ -54,12 +68,27 @@ struct Mlp1Lds {
 // Callers put a barrier between staging WS / finishing Himg and this, and before re-staging WS.
 __device__ __forceinline__ f32x4 m1_reduce_units(Mlp1Lds& s, const float (*Himg)[M1_HS], f32x4 acc, int wave, int lane) {
     const int b = wave & 1, kh = wave >> 1, n = lane & 15, kq = lane >> 4;
-#pragma unroll 8
-    for (int q = 32 * kh; q < 32 * kh + 32; ++q) {
-        const int u = 4 * q + kq;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(s.WS[u][n], Himg[u][16 * b + n], acc, 0, 0, 0);
+    // 32 k-steps of 4 units in chunks of 8; the operands of chunk c + 1 are read while chunk c is multiplied (hipcc left
+    // alone issues ds_read, s_waitcnt lgkmcnt(0), v_mfma per step: ~2 us per pass instead of ~0.6); two accumulator chains
+    float av[2][8], bv[2][8];
+    auto fetch = [&](int set, int q0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int u = 4 * (q0 + i) + kq; av[set][i] = s.WS[u][n]; bv[set][i] = Himg[u][16 * b + n]; }
+    };
+    f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+    fetch(0, 32 * kh);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c + 1 < 4) fetch((c + 1) & 1, 32 * kh + 8 * (c + 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][i], bv[c & 1][i], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][i + 1], bv[c & 1][i + 1], acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
-    return acc;
+    return acc + acc1;
 }
 __device__ __forceinline__ f32x4 m1_meet_halves(Mlp1Lds& s, f32x4 acc, int wave, int lane) {
     const int b = wave & 1, kh = wave >> 1;
@@ -67,6 +96,18 @@ __device__ __forceinline__ f32x4 m1_meet_halves(Mlp1Lds& s, f32x4 acc, int wave,
     __syncthreads();
     if (kh == 0) acc += *reinterpret_cast<const f32x4*>(s.TMP[b][lane]);
     return acc;
+}
+
+// rows s4 .. s4 + 3 of a [sample][16] image, N (8 or 16) features each, into registers: all reads issued back to back
+template <int N>
+__device__ __forceinline__ void m1_rows4(const float (*img)[M1_FS], int s4, float (&r)[4][N]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < N; c += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&img[s4 + u][c]);
+            r[u][c] = v[0]; r[u][c + 1] = v[1]; r[u][c + 2] = v[2]; r[u][c + 3] = v[3];
+        }
 }
 
 template <int DP, int LP, bool SIG>
@@ -78,36 +119,54 @@ __global__ __launch_bounds__(M1_NT) void mlp1_fused_kernel(const Mlp1Args a) {
     const float* const P = a.params;
     const bool je = j < a.He, jd = j < a.Hd;
     if (blockIdx.x == 0 && j == 0 && a.step_dev) a.step_dev[0] += 1;
+    M1_STAMP(0);
 
     // ---- this unit's weights (zero for units / features that do not exist: they then contribute nothing anywhere)
+    // (every load unconditional at a clamped index, the selects afterwards: hipcc waits for a conditional load where it is issued,
+    // which made this block a chain of ~45 memory round trips)
     float we1[DP], we2[LP], wd1[LP], wd2[DP], ws1[LP], ws2[DP];
-    const float be1 = je ? P[a.off_e1b + j] : 0.f, bd1 = jd ? P[a.off_d1b + j] : 0.f, bs1 = (SIG && jd) ? P[a.off_s1b + j] : 0.f;
+    const int jce = min(j, a.He - 1), jcd = min(j, a.Hd - 1);
+    const int s1w = SIG ? a.off_s1w : a.off_d1w, s2w = SIG ? a.off_s2w : a.off_d2w, s1b = SIG ? a.off_s1b : a.off_d1b,
+              s2b = SIG ? a.off_s2b : a.off_d2b;
+    float be1 = P[a.off_e1b + jce], bd1 = P[a.off_d1b + jcd], bs1 = P[s1b + jcd];
 #pragma unroll
     for (int k = 0; k < DP; ++k) {
-        we1[k] = (je && k < D) ? P[a.off_e1w + k * a.He + j] : 0.f;
-        wd2[k] = (jd && k < D) ? P[a.off_d2w + j * D + k] : 0.f;
-        ws2[k] = (SIG && jd && k < D) ? P[a.off_s2w + j * D + k] : 0.f;
+        const int kc = min(k, D - 1);
+        we1[k] = P[a.off_e1w + kc * a.He + jce]; wd2[k] = P[a.off_d2w + jcd * D + kc]; ws2[k] = P[s2w + jcd * D + kc];
     }
 #pragma unroll
     for (int l = 0; l < LP; ++l) {
-        we2[l] = (je && l < L) ? P[a.off_e2w + j * L + l] : 0.f;
-        wd1[l] = (jd && l < L) ? P[a.off_d1w + l * a.Hd + j] : 0.f;
-        ws1[l] = (SIG && jd && l < L) ? P[a.off_s1w + l * a.Hd + j] : 0.f;
+        const int lc = min(l, L - 1);
+        we2[l] = P[a.off_e2w + jce * L + lc]; wd1[l] = P[a.off_d1w + lc * a.Hd + jcd]; ws1[l] = P[s1w + lc * a.Hd + jcd];
     }
     // small vectors every epilogue lane needs: biases of the reducing layers, e^{lv/2}, for features 4 g .. 4 g + 3
     const int f0 = 4 * (lane >> 4);
     float be2[4], bd2[4], bs2[4], shl[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int f = f0 + r;
-        be2[r] = f < L ? P[a.off_e2b + f] : 0.f;
-        bd2[r] = f < D ? P[a.off_d2b + f] : 0.f;
-        bs2[r] = (SIG && f < D) ? P[a.off_s2b + f] : 0.f;
-        shl[r] = f < L ? expf(0.5f * P[a.off_epsp + f]) : 0.f;
+        const int f = f0 + r, fl = min(f, L - 1), fd = min(f, D - 1);
+        be2[r] = P[a.off_e2b + fl]; bd2[r] = P[a.off_d2b + fd]; bs2[r] = P[s2b + fd]; shl[r] = P[a.off_epsp + fl];
     }
-    const float eps = a.off_eps >= 0 ? P[a.off_eps] * a.eps_cli : a.eps_cli;
+    const float eps_ld = P[a.off_eps >= 0 ? a.off_eps : 0];
+    be1 = je ? be1 : 0.f; bd1 = jd ? bd1 : 0.f; bs1 = (SIG && jd) ? bs1 : 0.f;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+        we1[k] = (je && k < D) ? we1[k] : 0.f; wd2[k] = (jd && k < D) ? wd2[k] : 0.f; ws2[k] = (SIG && jd && k < D) ? ws2[k] : 0.f;
+    }
+#pragma unroll
+    for (int l = 0; l < LP; ++l) {
+        we2[l] = (je && l < L) ? we2[l] : 0.f; wd1[l] = (jd && l < L) ? wd1[l] : 0.f; ws1[l] = (SIG && jd && l < L) ? ws1[l] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int f = f0 + r;
+        be2[r] = f < L ? be2[r] : 0.f; bd2[r] = f < D ? bd2[r] : 0.f; bs2[r] = (SIG && f < D) ? bs2[r] : 0.f;
+        shl[r] = f < L ? expf(0.5f * shl[r]) : 0.f;
+    }
+    const float eps = a.off_eps >= 0 ? eps_ld * a.eps_cli : a.eps_cli;
     const float sigma = expf(0.5f * eps), inv_var = expf(-eps);
 
+    M1_STAMP(1);
     // ---- gradient accumulators of this unit (registers, across all tiles of this workgroup)
     float g_we1[DP], g_we2[LP], g_wd1[LP], g_wd2[DP], g_ws1[LP], g_ws2[DP];
     float g_be1 = 0.f, g_bd1 = 0.f, g_bs1 = 0.f;
@@ -123,24 +182,40 @@ __global__ __launch_bounds__(M1_NT) void mlp1_fused_kernel(const Mlp1Args a) {
         const int row0 = tile * M1_TS, valid = min(M1_TS, a.B - row0);
         __syncthreads();                                   // the previous tile's images are no longer read
         // ---- inputs, zero-padded to [32][16]
-        for (int e = j; e < M1_TS * M1_FS; e += M1_NT) {
-            const int r = e / M1_FS, c = e % M1_FS;
-            const bool in = r < valid;
-            const long long row = row0 + (in ? r : 0);
-            (&s.X[0][0])[e] = (in && c < D) ? a.x[row * D + c] : 0.f;
-            (&s.Z1[0][0])[e] = (in && c < L) ? a.z1[row * L + c] : 0.f;
-            (&s.Z2[0][0])[e] = (in && c < D) ? a.z2[row * D + c] : 0.f;
+        {
+            float xv[2], z1v[2], z2v[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {                  // unconditional at clamped indices, selects afterwards
+                const int e = j + i * M1_NT, r = e / M1_FS, c = e % M1_FS;
+                const long long row = row0 + min(r, valid - 1);
+                xv[i] = a.x[row * D + min(c, D - 1)]; z1v[i] = a.z1[row * L + min(c, L - 1)]; z2v[i] = a.z2[row * D + min(c, D - 1)];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = j + i * M1_NT, r = e / M1_FS, c = e % M1_FS;
+                const bool in = r < valid;
+                (&s.X[0][0])[e] = (in && c < D) ? xv[i] : 0.f;
+                (&s.Z1[0][0])[e] = (in && c < L) ? z1v[i] : 0.f;
+                (&s.Z2[0][0])[e] = (in && c < D) ? z2v[i] : 0.f;
+            }
         }
         __syncthreads();
+        M1_STAMP(2);
         // ---- encoder layer 1: HE[j][s] = relu(x[s] . We1[:, j] + be1[j])
+        // (per group of 4 samples the broadcast operand rows are read into registers first, then used: hipcc otherwise waits out
+        // the LDS latency per product.  Reading the NEXT group's rows under the current group's arithmetic was tried in all four
+        // per-unit loops: the second register set spills -- 3 to 11 KB of scratch, 240 us per step.)
 #pragma unroll 2
         for (int s4 = 0; s4 < M1_TS; s4 += 4) {
+            float xr[4][DP];
+            m1_rows4<DP>(s.X, s4, xr);
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 h;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 float acc = be1;
 #pragma unroll
-                for (int k = 0; k < DP; ++k) acc = fmaf(s.X[s4 + u][k], we1[k], acc);
+                for (int k = 0; k < DP; ++k) acc = fmaf(xr[u][k], we1[k], acc);
                 h[u] = fmaxf(acc, 0.f);
             }
             *reinterpret_cast<f32x4*>(&s.HE[j][s4]) = h;
@@ -148,6 +223,7 @@ __global__ __launch_bounds__(M1_NT) void mlp1_fused_kernel(const Mlp1Args a) {
 #pragma unroll
         for (int l = 0; l < M1_FS; ++l) s.WS[j][l] = l < LP ? we2[l < LP ? l : 0] : 0.f;
         __syncthreads();
+        M1_STAMP(3);
         // ---- mu = HE^T We2 + be2; samples = mu + e^{lv/2} z1
         {
             f32x4 acc = m1_reduce_units(s, s.HE, f32x4{0.f, 0.f, 0.f, 0.f}, wave, lane);
@@ -164,16 +240,20 @@ __global__ __launch_bounds__(M1_NT) void mlp1_fused_kernel(const Mlp1Args a) {
             }
         }
         __syncthreads();
+        M1_STAMP(4);
         // ---- decoder(s) layer 1
 #pragma unroll 2
         for (int s4 = 0; s4 < M1_TS; s4 += 4) {
+            float sr[4][LP];
+            m1_rows4<LP>(s.SMP, s4, sr);
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 h, hs;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 float acc = bd1, accs = bs1;
 #pragma unroll
                 for (int l = 0; l < LP; ++l) {
-                    const float sv = s.SMP[s4 + u][l];
+                    const float sv = sr[u][l];
                     acc = fmaf(sv, wd1[l], acc);
                     if (SIG) accs = fmaf(sv, ws1[l], accs);
                 }
@@ -185,6 +265,7 @@ __global__ __launch_bounds__(M1_NT) void mlp1_fused_kernel(const Mlp1Args a) {
 #pragma unroll
         for (int k = 0; k < M1_FS; ++k) s.WS[j][k] = k < DP ? wd2[k < DP ? k : 0] : 0.f;
         __syncthreads();
+        M1_STAMP(5);
         // ---- x_hat (linear decoder) = HD^T Wd2 + bd2
         {
             f32x4 acc = m1_reduce_units(s, s.HD, f32x4{0.f, 0.f, 0.f, 0.f}, wave, lane);
@@ -213,6 +294,7 @@ __global__ __launch_bounds__(M1_NT) void mlp1_fused_kernel(const Mlp1Args a) {
             }
         }
         __syncthreads();
+        M1_STAMP(6);
         // ---- ELBO, elementwise over [32][16]: decoder noise, residual, dL/dx_hat, the sigmoid head's gradient, scalar sums
         for (int e = j; e < M1_TS * M1_FS; e += M1_NT) {
             const int r = e / M1_FS, c = e % M1_FS;
@@ -230,22 +312,28 @@ __global__ __launch_bounds__(M1_NT) void mlp1_fused_kernel(const Mlp1Args a) {
             }
         }
         __syncthreads();
+        M1_STAMP(7);
         // ---- decoder(s) backward through layer 2 and the relu; the activation images become gradient images
 #pragma unroll 2
         for (int s4 = 0; s4 < M1_TS; s4 += 4) {
             const f32x4 h = *reinterpret_cast<const f32x4*>(&s.HD[j][s4]);
             f32x4 hs = {0.f, 0.f, 0.f, 0.f}, dh, dhs;
             if (SIG) hs = *reinterpret_cast<const f32x4*>(&s.HSg[j][s4]);
+            float dyr[4][DP], dsr[4][SIG ? DP : 4], sr[4][LP];
+            m1_rows4<DP>(s.DY, s4, dyr);
+            if (SIG) m1_rows4<SIG ? DP : 4>(s.DYS, s4, dsr);
+            m1_rows4<LP>(s.SMP, s4, sr);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 float d1 = 0.f, d2 = 0.f;
 #pragma unroll
                 for (int k = 0; k < DP; ++k) {
-                    const float dyv = s.DY[s4 + u][k];
+                    const float dyv = dyr[u][k];
                     g_wd2[k] = fmaf(h[u], dyv, g_wd2[k]);
                     d1 = fmaf(dyv, wd2[k], d1);
                     if (SIG) {
-                        const float dsv = s.DYS[s4 + u][k];
+                        const float dsv = dsr[u][SIG ? k : 0];
                         g_ws2[k] = fmaf(hs[u], dsv, g_ws2[k]);
                         d2 = fmaf(dsv, ws2[k], d2);
                     }
@@ -255,7 +343,7 @@ __global__ __launch_bounds__(M1_NT) void mlp1_fused_kernel(const Mlp1Args a) {
                 g_bd1 += d1; g_bs1 += d2;
 #pragma unroll
                 for (int l = 0; l < LP; ++l) {
-                    const float sv = s.SMP[s4 + u][l];
+                    const float sv = sr[u][l];
                     g_wd1[l] = fmaf(sv, d1, g_wd1[l]);
                     if (SIG) g_ws1[l] = fmaf(sv, d2, g_ws1[l]);
                 }
@@ -267,6 +355,7 @@ __global__ __launch_bounds__(M1_NT) void mlp1_fused_kernel(const Mlp1Args a) {
 #pragma unroll
         for (int l = 0; l < M1_FS; ++l) s.WS[j][l] = l < LP ? wd1[l < LP ? l : 0] : 0.f;
         __syncthreads();
+        M1_STAMP(8);
         // ---- d samples = dHD^T Wd1^T (+ dHS^T Ws1^T); d mu = d samples + mu / Bt
         {
             f32x4 acc = m1_reduce_units(s, s.HD, f32x4{0.f, 0.f, 0.f, 0.f}, wave, lane);
@@ -289,25 +378,31 @@ __global__ __launch_bounds__(M1_NT) void mlp1_fused_kernel(const Mlp1Args a) {
             }
         }
         __syncthreads();
+        M1_STAMP(9);
         // ---- encoder backward
 #pragma unroll 2
         for (int s4 = 0; s4 < M1_TS; s4 += 4) {
             const f32x4 h = *reinterpret_cast<const f32x4*>(&s.HE[j][s4]);
+            float dmr[4][LP], xr[4][DP];
+            m1_rows4<LP>(s.DMU, s4, dmr);
+            m1_rows4<DP>(s.X, s4, xr);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 float d1 = 0.f;
 #pragma unroll
                 for (int l = 0; l < LP; ++l) {
-                    const float dm = s.DMU[s4 + u][l];
+                    const float dm = dmr[u][l];
                     g_we2[l] = fmaf(h[u], dm, g_we2[l]);
                     d1 = fmaf(dm, we2[l], d1);
                 }
                 d1 = h[u] > 0.f ? d1 : 0.f;
                 g_be1 += d1;
 #pragma unroll
-                for (int k = 0; k < DP; ++k) g_we1[k] = fmaf(s.X[s4 + u][k], d1, g_we1[k]);
+                for (int k = 0; k < DP; ++k) g_we1[k] = fmaf(xr[u][k], d1, g_we1[k]);
             }
         }
+        M1_STAMP(10);
         // ---- the small vectors: thread t < 16 sums feature t over the samples
         if (j < M1_FS) {
             for (int r = 0; r < M1_TS; ++r) {
@@ -318,6 +413,7 @@ __global__ __launch_bounds__(M1_NT) void mlp1_fused_kernel(const Mlp1Args a) {
         }
     }
 
+    M1_STAMP(11);
     // ---- this workgroup's partial row
     float* const row = a.partials + (long long)blockIdx.x * a.pstride;
     if (je) {
@@ -353,6 +449,7 @@ __global__ __launch_bounds__(M1_NT) void mlp1_fused_kernel(const Mlp1Args a) {
     __syncthreads();
     if (j < 3) row[a.P + j] = (s.RED[0][j] + s.RED[1][j]) + (s.RED[2][j] + s.RED[3][j]);
     if (j == 3) { row[a.P + 3] = 0.f; if (a.off_eps >= 0) row[a.off_eps] = 0.f; }
+    M1_STAMP(12);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
@@ -369,7 +466,7 @@ typedef void (*Mlp1Kernel)(const Mlp1Args);
 int mlp1_launch(vaek_ctx* c, const float* params, const float* x, const float* z1, const float* z2, float* partials, int pstride,
                 int32_t* step_dev, hipStream_t st) {
     Mlp1Args a{};
-    a.step_dev = step_dev;
+    a.step_dev = step_dev; a.stamps = c->dbg_stamps;
     a.x = x; a.z1 = z1; a.z2 = z2; a.params = params; a.partials = partials; a.pstride = pstride;
     a.B = c->B; a.D = c->D; a.L = c->L; a.He = c->cfg.enc_hidden[0]; a.Hd = c->cfg.dec_hidden[0];
     a.ntiles = (c->B + M1_TS - 1) / M1_TS;
