@@ -24,10 +24,11 @@ for i in range(6):
     eng.train_step(params, grads, m, v, step, *batches[i % 4], 1e-4)
 torch.cuda.synchronize()
 t = buf.cpu().numpy()
-names = ["weights -> registers", "small vectors, exp", "inputs -> LDS", "encoder layer 1", "mu (MFMA) + reparam", "decoder layer 1", "x_hat (2 MFMA passes) + sigmoid",
-         "ELBO elementwise", "decoder backward", "d samples (2 MFMA passes)", "encoder backward", "small vectors", "partial row + scalar sums"]
+names = ["weights, small vectors, exp -> registers", "inputs -> LDS", "encoder layer 1", "mu (MFMA) + reparam", "decoder(s) layer 1",
+         "x_hat (MFMA passes) + sigmoid", "ELBO elementwise", "decoder(s) backward", "d samples (MFMA passes)", "encoder backward",
+         "small vectors", "partial row + scalar sums"]
 print("workgroup 7 of fused_mlp1 (us, s_memrealtime; each stamp drains the wave's memory operations first):")
-for i, n in enumerate(names[:12]):
-    print(f"   {n:36s} {(t[i + 1] - t[i]) / 100.0:7.2f}")
+for i, n in enumerate(names):
+    print(f"   {n:42s} {(t[i + 1] - t[i]) / 100.0:7.2f}")
 print(f"   total {(t[12] - t[0]) / 100.0:.2f}")
 PY
