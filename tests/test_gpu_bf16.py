@@ -39,7 +39,7 @@ def test_bf16_dense_path_tracks_oracle(hidden, B, dataset):
     assert abs(got[eng.P] - loss) <= 2e-3 * abs(loss), (got[eng.P], loss)
     assert rel_err(got[:eng.P], O.flatten(cfg, g)) <= 2e-2
     # and it is genuinely a different arithmetic from the f32 path (the bf16 kernels ran)
-    e32 = engine_for(cfg, B)
+    e32 = engine_for(cfg, B, force_generic=True)          # (one-hidden-layer f32 models otherwise take the whole-network kernel)
     g32 = e32.new_flat(e32.grad_len)
     e32.grads_only(params, g32, step, dev(x), dev(z1), dev(z2))
     if len(hidden) >= 2:                       # a layer with both dims >= 64 exists -> the bf16 kernels ran
