@@ -307,6 +307,34 @@ __device__ __forceinline__ void lin_reduce(const float* partial_in, double* M_ou
     }
 }
 
+// two 32-output slices at once (the persistent form's reducers own two each): both slices' loads are in flight together, one
+// memory round trip per batch instead of two.  Same row groups, same order of additions as lin_reduce: bitwise its sums.
+__device__ __forceinline__ void lin_reduce_pair(const float* partial_in, double* M_out, int ntiles, char* smem, int rb0, int rb1, int no) {
+    double* sums = reinterpret_cast<double*>(smem);       // [2][16][32]
+    const int t = threadIdx.x, q = t & 31, rg = t >> 5, o0 = rb0 * 32 + q, o1 = rb1 * 32 + q;
+    const int rpg = (ntiles + 15) / 16, r_lo = rg * rpg, r_hi = min(ntiles, r_lo + rpg);
+    double s0 = 0.0, s1 = 0.0;
+    for (int r0 = r_lo; r0 < r_hi; r0 += 16) {
+        float ta[16], tb[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {                     // unconditional, clamped
+            const float* row = partial_in + (long long)min(r0 + u, r_hi - 1) * no;
+            ta[u] = ld_sc1(row + o0); tb[u] = ld_sc1(row + o1);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { s0 += r0 + u < r_hi ? (double)ta[u] : 0.0; s1 += r0 + u < r_hi ? (double)tb[u] : 0.0; }
+    }
+    sums[rg * 32 + q] = s0; sums[512 + rg * 32 + q] = s1;
+    __syncthreads();
+    if (t < 64) {
+        const int which = t >> 5;
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += sums[which * 512 + k * 32 + q];
+        st_sc1(M_out + (which ? o1 : o0), tot);
+    }
+}
+
 // ---- updater: gradients and loss from (M, parameters), Adam -----------------------------------------------------------------
 // R and E are never formed.  With S = E + [diag(s) | 0 | 0 | 0] (samples = S u) and r = Wd^T samples + bd - x + sigma z2:
 //     SM = S M                      (L x NF; S has D + 2 non-zeros per row)          Q = E M = SM - diag(s) M[z1 rows]
@@ -689,9 +717,11 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) { 
             lin_wait_count(a.cnt_stream + n, (unsigned)a.ntiles, a.status, (2u << 28) | ((unsigned)n << 16));
             LIN_NOWQ(r1);
             if (!(a.diag & 1))
-                for (int sub = ro; sub < NO / 32; sub += per_set) {        // 32 outputs at a time (a 128-output form reading 16 bytes per
-                    if (sub != ro) __syncthreads();                     // lane with sc1 buffer loads measured 8 % SLOWER per step)
-                    lin_reduce<true>(a.partial_base + (long long)n * a.ntiles * NO, a.M_base + (long long)n * NO, a.ntiles, lin_smem, sub, NO);
+                for (int sub = ro; sub < NO / 32; sub += 2 * per_set) {    // 32-output slices, two at a time where there are two (a 128-output
+                    if (sub != ro) __syncthreads();                     // form reading 16 bytes per lane with sc1 buffer loads measured 8 % SLOWER per step)
+                    const float* pin = a.partial_base + (long long)n * a.ntiles * NO;
+                    if (sub + per_set < NO / 32) lin_reduce_pair(pin, a.M_base + (long long)n * NO, a.ntiles, lin_smem, sub, sub + per_set, NO);
+                    else lin_reduce<true>(pin, a.M_base + (long long)n * NO, a.ntiles, lin_smem, sub, NO);
                 }
             lin_wait_vmcnt<0>();                               // every storing wave drains its write-through stores ...
             __syncthreads();                                   // ... before the one lane that signals for the workgroup
@@ -748,13 +778,13 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) { 
     }
 }
 
-// device tables of batch pointers (the persistent kernel reads them; 48 pointers per launch keep the kernarg small).  The
-// first table launch of a persistent launch also zeroes its arrival counters and status word (a kernel of this stream rather
+// device tables of batch pointers (the persistent kernel reads them; 1.5 KB of kernarg).  The
+// table launch of a persistent launch also zeroes its arrival counters and status word (a kernel of this stream rather
 // than a memset node: it stays an ordinary kernel node when the call is captured into a hipGraph).
-struct LinTable { const float* x[16]; const float* z1[16]; const float* z2[16]; int n, base; unsigned* zero; };
+struct LinTable { const float* x[kLinMaxPersist]; const float* z1[kLinMaxPersist]; const float* z2[kLinMaxPersist]; int n; unsigned* zero; };
 __global__ void lin_table_kernel(const LinTable tb, const float** xs, const float** z1s, const float** z2s) {
     const int i = threadIdx.x;
-    if (i < tb.n) { xs[tb.base + i] = tb.x[i]; z1s[tb.base + i] = tb.z1[i]; z2s[tb.base + i] = tb.z2[i]; }
+    if (i < tb.n) { xs[i] = tb.x[i]; z1s[i] = tb.z1[i]; z2s[i] = tb.z2[i]; }
     if (tb.zero)
         for (int k = i; k < 1024; k += 64) tb.zero[k] = 0u;
 }
@@ -854,10 +884,10 @@ int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v
         for (int s0 = 0; s0 < n_steps; s0 += kLinMaxPersist) {
             const int n = std::min(kLinMaxPersist, n_steps - s0);
             const float** txs = w.tab; const float** tz1 = w.tab + kLinMaxPersist; const float** tz2 = w.tab + 2 * kLinMaxPersist;
-            for (int b0 = 0; b0 < n; b0 += 16) {
+            {
                 LinTable tb{};
-                tb.n = std::min(16, n - b0); tb.base = b0; tb.zero = b0 == 0 ? w.cnt : nullptr;
-                for (int i = 0; i < tb.n; ++i) { tb.x[i] = xs[s0 + b0 + i]; tb.z1[i] = z1s[s0 + b0 + i]; tb.z2[i] = z2s[s0 + b0 + i]; }
+                tb.n = n; tb.zero = w.cnt;
+                for (int i = 0; i < n; ++i) { tb.x[i] = xs[s0 + i]; tb.z1[i] = z1s[s0 + i]; tb.z2[i] = z2s[s0 + i]; }
                 hipLaunchKernelGGL(lin_table_kernel, dim3(1), dim3(64), 0, st, tb, txs, tz1, tz2);
             }
             LinArgs a{};
