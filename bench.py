@@ -307,7 +307,9 @@ def main():
     # reads its own batch once, computes loss and gradients at the CURRENT parameters and applies Adam, but evaluated through
     # the batch's second-moment matrix, so that launch n streams batch n while it sums batch n - 1 and updates with batch n - 2
     # (csrc/linear_moments.hip).  Everything else: one vaek_train_step per step.
-    use_pipe = exch is None and not args.no_pipeline and eng.supports_train_steps()
+    # Data parallel: the moment matrix is additive over ranks and is exchanged inside the persistent launch over the P2P
+    # communicator (same kernel at every N); without that communicator (RCCL transport) N > 1 takes the per-sample step.
+    use_pipe = (exch is None or exch.in_library) and not args.no_pipeline and eng.supports_train_steps()
 
     def run_group(i0, n):
         """n consecutive train steps on batches i0, i0 + 1, ... (mod the rotation)."""
@@ -339,6 +341,15 @@ def main():
     graph = None
     n_warm_eager = max(args.warmup, 3)
     run_group(0, n_warm_eager)
+    if use_pipe and dist is not None:
+        # the in-launch exchange has never met this topology before: all ranks agree that no bounded wait expired, or all fall
+        # back to the per-sample step with the gradient exchange
+        torch.cuda.synchronize()
+        bad = torch.tensor([1.0 if eng.train_steps_gave_up() else 0.0], device="cpu" if args.rehearse_one_gpu else device)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if float(bad.item()) != 0.0:
+            use_pipe = False
+            run_group(0, n_warm_eager)
     if gsteps > 0:
         torch.cuda.synchronize()
         side = torch.cuda.Stream()

@@ -133,3 +133,71 @@ def test_p2p_exchange_gives_up_on_a_silent_peer_and_then_fails_fast():
     assert timed_out
     assert 0.2 < t_first < 30.0, t_first          # ~3 s at ~0.4 us per poll; generous bounds, but not minutes
     assert t_second < 0.5 * t_first and t_second < 1.0, (t_first, t_second)
+
+
+def _steps_worker(rank, world, port, q):
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        from vae_training_amd.engine import Engine
+        from vae_training_amd.parallel import GradExchange, shard_rows
+        cfg = O.Config(12, 20, (), (), -1.0, True, "linear_gaussian")
+        B, lr, steps = 1536, 1e-3, 7
+        rng = np.random.default_rng(0)
+        r32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+        p = {k: r32(v) for k, v in O.init_params(cfg, seed=0).items()}
+        xs = [r32(rng.standard_normal((B, 12))) for _ in range(steps)]
+        zs = [r32(rng.standard_normal((B, 32))) for _ in range(steps)]
+        lo, hi = shard_rows(B, world, rank)
+        eng = Engine(hi - lo, 12, 20, (), (), -1.0, True, False, world=world, rank=rank, global_batch=B)
+        assert not eng.supports_train_steps()              # no communicator yet: the moments cannot be exchanged
+        ex = GradExchange(eng, dist, mode="p2p")
+        assert ex.in_library and eng.supports_train_steps()
+        dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda()
+        params = dev(O.flatten(cfg, p)); grads = eng.new_flat(eng.grad_len); m = eng.new_flat(); v = eng.new_flat()
+        step = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ring = torch.zeros(steps + 4, dtype=torch.float32, device="cuda")
+        eng.set_loss_history(ring)
+        st, want = O.adam_init(p), []
+        batches = []
+        for s in range(steps):
+            z1, z2 = O.split_latents(zs[s], 20)
+            p, st, loss_ref = O.train_step(cfg, p, st, xs[s], z1, z2, lr)          # full batch on the oracle
+            want.append(loss_ref)
+            batches.append((dev(xs[s][lo:hi]), dev(z1[lo:hi]), dev(z2[lo:hi])))
+        eng.train_steps(params, grads, m, v, step, batches[:4], lr)                # two launches: 4 + 3 steps
+        eng.train_steps(params, grads, m, v, step, batches[4:], lr)
+        torch.cuda.synchronize()
+        got = ring.cpu().numpy()[:steps].astype(np.float64)
+        worst = float(np.max(np.abs(got - np.array(want)) / np.abs(want)))
+        perr = float(np.max(np.abs(params.cpu().numpy().astype(np.float64) - O.flatten(cfg, p))))
+        digest = torch.tensor(params.cpu().numpy().view(np.int32).astype(np.int64).sum().reshape(1))
+        allg = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(allg, digest)
+        q.put((rank, worst, perr, all(int(a) == int(allg[0]) for a in allg), eng.train_steps_gave_up() or int(step.item()) != steps, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, 1.0, 1.0, False, True, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipelined_steps_exchange_their_moments_across_ranks(world):
+    """vaek_train_steps under data parallelism: each rank streams its shard, the reducers exchange the moment matrix over the
+    P2P communicator inside the persistent launch, every rank applies the same update -- losses and parameters follow the
+    oracle's FULL-batch training, replicas end bitwise identical, no bounded wait expires (ranks rehearsed on one GPU)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_steps_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, lerr, perr, same, bad, tb in res:
+        assert tb is None, tb
+        assert lerr <= 1e-5 and perr <= 0.02 * 1e-3 * 7 and same and not bad, (rank, lerr, perr, same, bad)

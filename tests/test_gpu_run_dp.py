@@ -78,4 +78,6 @@ def test_bench_py_two_ranks_rehearsed_on_one_gpu(comm, port):
     assert out["config"]["global_batch"] == 2 * out["config"]["batch_per_gpu"]
     assert np.isfinite(out["value"]) and out["value"] > 0 and np.isfinite(out["config"]["final_loss"]), out
     assert out["config"]["grad_exchange"] == comm, out["config"]
-    assert out["config"]["step_entry_point"] == "vaek_train_step"      # vaek_train_steps is single-GPU for now
+    # P2P transport: the moments are exchanged inside the persistent launch; RCCL transport: the per-sample step + all-reduce
+    assert out["config"]["step_entry_point"].startswith("vaek_train_steps" if comm == "p2p" else "vaek_train_step")
+    assert (comm == "p2p") == ("persistent" in out["config"]["step_entry_point"])

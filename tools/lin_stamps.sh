@@ -22,7 +22,8 @@ step = torch.zeros(1, dtype=torch.int32, device="cuda")
 batches = make_batches(w, B, eng.device, 48 if persist else 4, seed=1)
 buf = torch.zeros(256, dtype=torch.int64, device="cuda")
 assert eng.lib.vaek_debug_lin_stamps(C.c_void_p(buf.data_ptr())) == 0
-for nsteps in ((40, 64, 64) if persist else (4, 4, 4)):
+NS = int(os.environ.get("LIN_NSTEPS", 64))
+for nsteps in ((40, NS, NS) if persist else (4, 4, 4)):
     buf.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -40,7 +41,7 @@ if persist:
     print(f"   reducer workgroup 5 (32 of the launch's batches): waiting {t[40] / 100.0:.1f} us, reducing {t[41] / 100.0:.1f} us")
     print(f"   streamer 7 ({t[46]} work items), us per item: issue next {t[42] / 100.0 / t[46]:.2f}, wait for the tile {t[43] / 100.0 / t[46]:.2f}, fix {t[44] / 100.0 / t[46]:.2f}, multiply + barrier {t[45] / 100.0 / t[46]:.2f}")
     print("   batch: reduced at | updated at  (us after the updater entered its loop; last arrival of each role)")
-    for n in range(0, 64, 3):
+    for n in range(0, nsteps, 1 if nsteps <= 24 else 3):
         print(f"   {n:3d}   {(t[128 + n] - t0) / 100.0:8.1f}   {(t[64 + n] - t0) / 100.0:8.1f}")
     print("updater, last step of the launch (s_memtime ticks):")
     print(f"   publish params               {t[9] - t[0]:8d}")

@@ -35,7 +35,7 @@ int vaek_comm_buffer_bytes(const vaek_ctx* ctx, size_t* bytes) {
     if (!ctx || !bytes) { set_error("null argument"); return VAEK_ERR_INVALID; }
     const size_t ng = (size_t)((ctx->P + kExtra + 63) / 64 * 64);
     // two regions (train step: epoch = Adam step; stand-alone all-reduce: its own epochs) + status line
-    *bytes = 2 * (2ull * ctx->cfg.world * ng) * sizeof(unsigned long long) + 256;
+    *bytes = 2 * (2ull * ctx->cfg.world * ng) * sizeof(unsigned long long) + 256 + lin_comm_bytes(ctx);
     return VAEK_OK;
 }
 
@@ -71,6 +71,8 @@ int vaek_comm_create(vaek_ctx* ctx, uint8_t handle_out[64]) {
     ctx->comm.local = p;
     ctx->comm.ng = (int)((ctx->P + kExtra + 63) / 64 * 64);
     ctx->comm.bytes = bytes;
+    ctx->comm.lin_bytes = lin_comm_bytes(ctx);
+    ctx->comm.lin_off = bytes - ctx->comm.lin_bytes;          // behind the two granule regions and the 256-byte status line
     return VAEK_OK;
 }
 

@@ -39,6 +39,7 @@
 // different summation order, so this path is NOT bitwise comparable with vaek_train_step.
 #include <stdlib.h>
 
+#include "comm_dev.h"
 #include "vaek_internal.h"
 
 namespace vaek {
@@ -53,6 +54,15 @@ constexpr int kLinMaxPersist = 64;                // steps per persistent launch
 constexpr int kLinReduceSets = 1;                 // persistent form: reducer sets taking alternate batches (one set of 24 beat two of 12)
 constexpr int kLinReduceWgs = 24;                 // workgroups per set, each summing NO / 32 / 24 slices of 32 outputs (more resident
                                                   // workgroups measurably slow the streamers: 48 per set cost 2 us per step)
+
+// Data parallel (world > 1): the moment matrix is additive over ranks.  Each reducer publishes its slice of the rank's M to every
+// rank's exchange buffer (comm_dev.h's scheme: 8-byte granules {tag = the batch's Adam step, 32 bits of payload} in uncached,
+// IPC-mapped memory, one aligned system-scope store each -- the data is the flag), waits for the same slice from all ranks in
+// its own buffer, and adds them in rank order: every rank ends with the same bits, and the updater never learns that other
+// ranks exist.  A double travels as two granules.  A reducer cannot get more than one batch ahead of a peer's (it needs that
+// peer's granules to finish a batch), so banks by tag & 3 are never overwritten before they are read.
+constexpr int kLinCommBanks = 4;
+struct LinComm { unsigned long long* peer[kMaxWorld]; int world, rank, ng2; };     // ng2 = granules per (bank, source rank) = 2 NO
 
 struct LinArgs {
     // roles by blockIdx.x: [0, has_update) the updater, then n_reduce reducers, then n_stream streamers
@@ -71,6 +81,7 @@ struct LinArgs {
     float* params; float* grads; float* m; float* v; int32_t* step_dev; float lr;
     float inv_bt, eps_cli, rows, rows_over_bt; int off_eps, P;
     float* loss_hist; long long loss_hist_cap;
+    LinComm comm;
 };
 
 #ifdef VAEK_LIN_STAMPS      // diagnostic build (tools/lin_stamps.sh): s_memtime at the updater's phase boundaries, into a buffer nothing reads
@@ -153,6 +164,41 @@ __device__ __forceinline__ void lin_wait_count(const unsigned* cnt, unsigned tar
         }
     }
     __syncthreads();
+}
+
+// one output of M across the ranks: publish this rank's value, collect everybody's, add in rank order (bounded spins)
+__device__ __forceinline__ double lin_sum_over_ranks(const LinComm& c, unsigned epoch, int o, double v, unsigned* status) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v), tag = (unsigned long long)epoch << 32;
+    const long long bank = (long long)(epoch & (kLinCommBanks - 1)) * c.world * c.ng2;
+    for (int p = 0; p < c.world; ++p) {
+        unsigned long long* q = c.peer[p] + bank + (long long)c.rank * c.ng2 + 2 * o;
+        __hip_atomic_store(q, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(q + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const unsigned long long* own = c.peer[c.rank] + bank + 2 * o;
+    double sum = 0.0;
+    unsigned spins = 0;
+    bool dead = false;
+    for (int r = 0; r < c.world; ++r) {
+        unsigned long long lo = 0, hi = 0;
+        for (;;) {
+            lo = __hip_atomic_load(own + (long long)r * c.ng2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            hi = __hip_atomic_load(own + (long long)r * c.ng2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (((unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch) || dead) break;
+            __builtin_amdgcn_s_sleep(8);
+            if ((++spins & 1023u) == 0) {
+                if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) dead = true;
+                else if (spins > (1u << 21)) {
+                    unsigned expect = 0;
+                    __hip_atomic_compare_exchange_strong(status, &expect, 0x80000000u | (3u << 28) | ((unsigned)r << 16) | (epoch & 0xffffu),
+                                                         __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    dead = true;
+                }
+            }
+        }
+        sum += __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+    }
+    return sum;
 }
 
 // ---- streamer pieces ------------------------------------------------------------------------------------------------------------
@@ -281,7 +327,8 @@ __device__ __forceinline__ void lin_multiply_tile(const LinArgs& a, const LinSlo
 
 // ---- reducer: 32 outputs x 16 row groups per workgroup, float64, fixed order ------------------------------------------------
 template <bool SC1>
-__device__ __forceinline__ void lin_reduce(const float* partial_in, double* M_out, int ntiles, char* smem, int rb, int no) {
+__device__ __forceinline__ void lin_reduce(const float* partial_in, double* M_out, int ntiles, char* smem, int rb, int no,
+                                           const LinComm* cm = nullptr, unsigned epoch = 0, unsigned* status = nullptr) {
     double* sums = reinterpret_cast<double*>(smem);       // [16][32]
     const int t = threadIdx.x, o = rb * 32 + (t & 31), rg = t >> 5;
     const int rpg = (ntiles + 15) / 16, r_lo = rg * rpg, r_hi = min(ntiles, r_lo + rpg);
@@ -303,13 +350,15 @@ __device__ __forceinline__ void lin_reduce(const float* partial_in, double* M_ou
         double tot = 0.0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) tot += sums[k * 32 + t];
+        if (cm && cm->world > 1) tot = lin_sum_over_ranks(*cm, epoch, o, tot, status);
         if (SC1) st_sc1(M_out + o, tot); else M_out[o] = tot;
     }
 }
 
 // two 32-output slices at once (the persistent form's reducers own two each): both slices' loads are in flight together, one
 // memory round trip per batch instead of two.  Same row groups, same order of additions as lin_reduce: bitwise its sums.
-__device__ __forceinline__ void lin_reduce_pair(const float* partial_in, double* M_out, int ntiles, char* smem, int rb0, int rb1, int no) {
+__device__ __forceinline__ void lin_reduce_pair(const float* partial_in, double* M_out, int ntiles, char* smem, int rb0, int rb1, int no,
+                                                const LinComm& cm, unsigned epoch, unsigned* status) {
     double* sums = reinterpret_cast<double*>(smem);       // [2][16][32]
     const int t = threadIdx.x, q = t & 31, rg = t >> 5, o0 = rb0 * 32 + q, o1 = rb1 * 32 + q;
     const int rpg = (ntiles + 15) / 16, r_lo = rg * rpg, r_hi = min(ntiles, r_lo + rpg);
@@ -331,6 +380,7 @@ __device__ __forceinline__ void lin_reduce_pair(const float* partial_in, double*
         double tot = 0.0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) tot += sums[which * 512 + k * 32 + q];
+        if (cm.world > 1) tot = lin_sum_over_ranks(cm, epoch, which ? o1 : o0, tot, status);
         st_sc1(M_out + (which ? o1 : o0), tot);
     }
 }
@@ -711,6 +761,7 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) { 
     } else if (b < a.has_update + a.n_reduce) {
         // ---- reducers: set (rb / per_set) takes batches set, set + 2, ... ------------------------------------------------------
         const int rb = b - a.has_update, set = rb / per_set, ro = rb % per_set;
+        const int tstep0 = a.step_dev[0];              // (the updater stores the counter at the very end of the launch)
         [[maybe_unused]] unsigned long long r0 = 0, r1 = 0, r2 = 0, racc_w = 0, racc_r = 0;
         for (int n = set; n < N; n += a.sets) {
             LIN_NOWQ(r0);
@@ -720,8 +771,10 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) { 
                 for (int sub = ro; sub < NO / 32; sub += 2 * per_set) {    // 32-output slices, two at a time where there are two (a 128-output
                     if (sub != ro) __syncthreads();                     // form reading 16 bytes per lane with sc1 buffer loads measured 8 % SLOWER per step)
                     const float* pin = a.partial_base + (long long)n * a.ntiles * NO;
-                    if (sub + per_set < NO / 32) lin_reduce_pair(pin, a.M_base + (long long)n * NO, a.ntiles, lin_smem, sub, sub + per_set, NO);
-                    else lin_reduce<true>(pin, a.M_base + (long long)n * NO, a.ntiles, lin_smem, sub, NO);
+                    const unsigned epoch = (unsigned)(tstep0 + n + 1);      // the batch's Adam step: the tag of its exchange granules
+                    if (sub + per_set < NO / 32)
+                        lin_reduce_pair(pin, a.M_base + (long long)n * NO, a.ntiles, lin_smem, sub, sub + per_set, NO, a.comm, epoch, a.status);
+                    else lin_reduce<true>(pin, a.M_base + (long long)n * NO, a.ntiles, lin_smem, sub, NO, &a.comm, epoch, a.status);
                 }
             lin_wait_vmcnt<0>();                               // every storing wave drains its write-through stores ...
             __syncthreads();                                   // ... before the one lane that signals for the workgroup
@@ -794,9 +847,17 @@ __global__ void lin_table_kernel(const LinTable tb, const float** xs, const floa
 static int lin_nb(const vaek_ctx* c) { return (c->L + 2 * c->D + 1 + 15) / 16 <= 3 ? 3 : 4; }
 static int lin_no(const vaek_ctx* c) { const int NB = lin_nb(c); return NB * (NB + 1) / 2 * 256; }
 
-bool lin_steps_supported(const vaek_ctx* c) {
+// the model / batch shapes the moment formulation covers (whatever the number of ranks)
+static bool lin_steps_shape_ok(const vaek_ctx* c) {
     return c->cfg.n_enc_hidden == 0 && c->cfg.n_dec_hidden == 0 && !c->cfg.sigmoid_decoder && c->cfg.dtype == VAEK_F32 &&
-           c->cfg.world == 1 && c->L + 2 * c->D + 1 <= 64 && (long long)c->B * std::min(c->D, c->L) >= 8;
+           c->L + 2 * c->D + 1 <= 64 && (long long)c->B * std::min(c->D, c->L) >= 8;
+}
+static bool lin_persist_supported(const vaek_ctx* c);
+// data parallel: the persistent form only, and only once the P2P communicator (vaek_comm_create / _init) carries the moment region
+bool lin_steps_supported(const vaek_ctx* c) {
+    if (!lin_steps_shape_ok(c)) return false;
+    if (c->cfg.world == 1) return true;
+    return lin_persist_supported(c) && c->comm.ready && c->comm.lin_bytes > 0;
 }
 static size_t lin_ring_bytes(const vaek_ctx* c, int T) {        // the streamers' two tile slots (each doubling as the multiply's scratch) + pointer tables
     const LinSlot sl(c->D, c->L, T);
@@ -829,7 +890,7 @@ static size_t lin_persist_lds(const vaek_ctx* c) {
 }
 static bool lin_persist_supported(const vaek_ctx* c) {
     const LinSlot sl(c->D, c->L, lin_tile_rows(c));
-    return lin_steps_supported(c) && lin_nb(c) == 3 && lin_persist_lds(c) <= 160 * 1024 && sl.passes <= 12 &&
+    return lin_steps_shape_ok(c) && lin_nb(c) == 3 && lin_persist_lds(c) <= 160 * 1024 && sl.passes <= 12 &&
            c->n_cu >= 1 + kLinReduceSets * kLinReduceWgs + 16;
 }
 // streamer workgroups of the persistent launch: the CUs the updater and the reducers leave, tiles dealt evenly
@@ -852,14 +913,28 @@ static LinWs lin_carve(const vaek_ctx* c, char* base) {
     w.total = (off + 255) / 256 * 256;
     return w;
 }
-size_t lin_steps_workspace_bytes(const vaek_ctx* c) { return lin_steps_supported(c) ? lin_carve(c, nullptr).total : 0; }
+size_t lin_steps_workspace_bytes(const vaek_ctx* c) { return lin_steps_shape_ok(c) ? lin_carve(c, nullptr).total : 0; }
+// bytes of the moment-exchange region of the P2P communicator's buffer (0: this context never exchanges moments)
+size_t lin_comm_bytes(const vaek_ctx* c) {
+    if (c->cfg.world < 2 || !lin_persist_supported(c)) return 0;
+    return (size_t)kLinCommBanks * c->cfg.world * 2 * lin_no(c) * sizeof(unsigned long long);
+}
 
 typedef void (*LinKernel)(const LinArgs);
 static int lin_fill_common(const vaek_ctx* c, LinArgs& a, float* params, float* grads, float* m, float* v, int32_t* step_dev, float lr) {
     a.B = c->B; a.D = c->D; a.L = c->L; a.T = lin_tile_rows(c); a.ntiles = lin_ntiles(c);
     a.params = params; a.grads = grads; a.m = m; a.v = v; a.step_dev = step_dev; a.lr = lr;
-    a.inv_bt = (float)(1.0 / (double)c->Bt); a.eps_cli = c->cfg.eps_cli; a.rows = (float)c->B;
-    a.rows_over_bt = (float)((double)c->B / (double)c->Bt); a.off_eps = (int)c->off_eps; a.P = (int)c->P;
+    // data parallel: M is summed over the ranks before the updater sees it, so its "rows" are the GLOBAL batch
+    const double rows = c->cfg.world > 1 ? (double)c->Bt : (double)c->B;
+    a.inv_bt = (float)(1.0 / (double)c->Bt); a.eps_cli = c->cfg.eps_cli; a.rows = (float)rows;
+    a.rows_over_bt = (float)(rows / (double)c->Bt); a.off_eps = (int)c->off_eps; a.P = (int)c->P;
+    a.comm = LinComm{};
+    a.comm.world = 1;
+    if (c->cfg.world > 1 && c->comm.ready && c->comm.lin_bytes > 0) {
+        a.comm.world = c->cfg.world; a.comm.rank = c->cfg.rank; a.comm.ng2 = 2 * lin_no(c);
+        for (int r = 0; r < c->cfg.world; ++r)
+            a.comm.peer[r] = reinterpret_cast<unsigned long long*>(static_cast<char*>(c->comm.peers[r]) + c->comm.lin_off);
+    }
     a.loss_hist = c->loss_hist; a.loss_hist_cap = c->loss_hist_cap;
     return 0;
 }
@@ -871,7 +946,7 @@ int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v
     // the metric's shape with its dimensions at compile time; every other linear model on the run-time instantiations
     const int which = (c->D == 12 && c->L == 20) ? 0 : (NB <= 3 ? 1 : 2);
     static const char* env = getenv("VAEK_LIN_PERSIST");              // diagnostic: 0 forces the launch-per-step form
-    const bool persistent = lin_persist_supported(c) && !(env && atoi(env) == 0);
+    const bool persistent = lin_persist_supported(c) && (c->cfg.world > 1 || !(env && atoi(env) == 0));   // data parallel: persistent form only
     const size_t lds = persistent ? lin_persist_lds(c) : lin_lds_need(c);
     const LinKernel fn = persistent ? (which == 0 ? lin_persist_kernel<3, 12, 20> : lin_persist_kernel<3, 0, 0>)
                                     : (which == 0 ? lin_step_kernel<3, 12, 20> : which == 1 ? lin_step_kernel<3, 0, 0> : lin_step_kernel<4, 0, 0>);
@@ -937,7 +1012,7 @@ int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v
 // synchronous: did a bounded wait of the persistent form ever give up (a workgroup that never became resident, a lost store)?
 int lin_steps_status(vaek_ctx* c, void* ws, int* gave_up) {
     *gave_up = 0;
-    if (!lin_steps_supported(c)) return VAEK_OK;
+    if (!lin_steps_shape_ok(c)) return VAEK_OK;
     const LinWs w = lin_carve(c, static_cast<char*>(ws) + c->ws_lin);
     unsigned s = 0;
     VAEK_HIP_CHECK(hipMemcpy(&s, w.cnt + 512, sizeof(s), hipMemcpyDeviceToHost));

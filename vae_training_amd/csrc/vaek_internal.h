@@ -86,6 +86,7 @@ struct Comm {
     int ng = 0;                 // granules per (bank, source rank)
     std::vector<void*> peers;   // world entries; peers[rank] == local, others IPC-mapped
     uint32_t epoch = 0;         // stand-alone all-reduce epochs (region 1)
+    size_t lin_off = 0, lin_bytes = 0;   // the moment-exchange region of vaek_train_steps (linear_moments.hip), behind the status line
 };
 
 }  // namespace vaek
@@ -277,6 +278,7 @@ int fused_mfma_launch(const vaek_ctx* c, const float* params, const void* fused_
 
 // ---- linear_moments.hip: N pipelined steps of a linear VAE through the batch's second-moment matrix --------------------
 bool lin_steps_supported(const vaek_ctx* c);
+size_t lin_comm_bytes(const vaek_ctx* c);
 size_t lin_steps_workspace_bytes(const vaek_ctx* c);
 int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v, int32_t* step_dev, const float* const* xs,
                     const float* const* z1s, const float* const* z2s, int n_steps, float lr, void* ws, hipStream_t st);
