@@ -223,7 +223,9 @@ int vaek_train_step_gen(vaek_ctx* ctx, float* params, float* grads, float* m, fl
  * the cross-workgroup sum of batch n + 1 and the Adam update of batch n run side by side -- as resident workgroup roles of one
  * persistent launch per 64 steps (arrival counters, bounded waits: vaek_train_steps_status), or where that form does not apply as
  * n_steps + 2 launches ordered by the stream alone.  Capturable into a hipGraph.  Linear encoder / decoder, one decoder, float32, L + 2 D + 1 <= 64,
- * single GPU: vaek_supports_train_steps says whether this context qualifies; others return VAEK_ERR_INVALID. */
+ * and, with world > 1, an initialised P2P communicator (vaek_comm_create / vaek_comm_init: the moment matrix is additive over the
+ * ranks' shards and is exchanged inside the launch; every rank must make the same calls, and the Adam step counter must not restart
+ * while the communicator lives): vaek_supports_train_steps says whether this context qualifies; others return VAEK_ERR_INVALID. */
 int vaek_supports_train_steps(const vaek_ctx* ctx, int32_t* yes);
 int vaek_train_steps(vaek_ctx* ctx, float* params, float* grads, float* m, float* v, int32_t* step_dev,
                      const float* const* xs, const float* const* z1s, const float* const* z2s, int32_t n_steps, float lr,
