@@ -120,6 +120,19 @@ __global__ __launch_bounds__(M1_NT) void mlp1_fused_kernel(const Mlp1Args a) {
     const bool je = j < a.He, jd = j < a.Hd;
     if (blockIdx.x == 0 && j == 0 && a.step_dev) a.step_dev[0] += 1;
     M1_STAMP(0);
+    // the inputs of a tile travel one tile ahead in registers (two elements of each [32][16] image per thread): the first tile's
+    // loads share the weights' memory round trip, later ones land under the previous tile's arithmetic
+    float xv[2], z1v[2], z2v[2];
+    auto fetch_inputs = [&](int tile) {
+        const int row0 = tile * M1_TS, valid = min(M1_TS, a.B - row0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                      // unconditional at clamped indices, selects when they are written to LDS
+            const int e = j + i * M1_NT, r = e / M1_FS, c = e % M1_FS;
+            const long long row = row0 + min(r, valid - 1);
+            xv[i] = a.x[row * a.D + min(c, a.D - 1)]; z1v[i] = a.z1[row * a.L + min(c, a.L - 1)]; z2v[i] = a.z2[row * a.D + min(c, a.D - 1)];
+        }
+    };
+    fetch_inputs(min((int)blockIdx.x, a.ntiles - 1));
 
     // ---- this unit's weights (zero for units / features that do not exist: they then contribute nothing anywhere)
     // (every load unconditional at a clamped index, the selects afterwards: hipcc waits for a conditional load where it is issued,
@@ -182,23 +195,15 @@ __global__ __launch_bounds__(M1_NT) void mlp1_fused_kernel(const Mlp1Args a) {
         const int row0 = tile * M1_TS, valid = min(M1_TS, a.B - row0);
         __syncthreads();                                   // the previous tile's images are no longer read
         // ---- inputs, zero-padded to [32][16]
-        {
-            float xv[2], z1v[2], z2v[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {                  // unconditional at clamped indices, selects afterwards
-                const int e = j + i * M1_NT, r = e / M1_FS, c = e % M1_FS;
-                const long long row = row0 + min(r, valid - 1);
-                xv[i] = a.x[row * D + min(c, D - 1)]; z1v[i] = a.z1[row * L + min(c, L - 1)]; z2v[i] = a.z2[row * D + min(c, D - 1)];
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int e = j + i * M1_NT, r = e / M1_FS, c = e % M1_FS;
-                const bool in = r < valid;
-                (&s.X[0][0])[e] = (in && c < D) ? xv[i] : 0.f;
-                (&s.Z1[0][0])[e] = (in && c < L) ? z1v[i] : 0.f;
-                (&s.Z2[0][0])[e] = (in && c < D) ? z2v[i] : 0.f;
-            }
+        for (int i = 0; i < 2; ++i) {
+            const int e = j + i * M1_NT, r = e / M1_FS, c = e % M1_FS;
+            const bool in = r < valid;
+            (&s.X[0][0])[e] = (in && c < D) ? xv[i] : 0.f;
+            (&s.Z1[0][0])[e] = (in && c < L) ? z1v[i] : 0.f;
+            (&s.Z2[0][0])[e] = (in && c < D) ? z2v[i] : 0.f;
         }
+        if (tile + (int)gridDim.x < a.ntiles) fetch_inputs(tile + gridDim.x);
         __syncthreads();
         M1_STAMP(2);
         // ---- encoder layer 1: HE[j][s] = relu(x[s] . We1[:, j] + be1[j])

@@ -781,6 +781,7 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) { 
             LIN_NOWQ(r2);
             racc_w += r1 - r0; racc_r += r2 - r1;
             if (rb == 5) { LIN_PUT(40, racc_w); LIN_PUT(41, racc_r); }
+            if (rb == 5 && n < 3) { LIN_PUT(56 + 2 * n, r1); LIN_PUT(57 + 2 * n, r2); }
             if (t == 0) __hip_atomic_fetch_add(a.cnt_reduce + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             { [[maybe_unused]] unsigned long long te = 0; LIN_NOW(te); LIN_PUTMAX(128 + n, te); }
         }
@@ -789,6 +790,7 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) { 
         // slots: the loads of work item i + 1 are in flight while item i is multiplied.  The batch pointers live in LDS (one
         // fetch per launch: a scalar load per batch would sit on the critical path with the memory system busy).
         const int sid = b - a.has_update - a.n_reduce, S = a.n_stream;
+        { [[maybe_unused]] unsigned long long te = 0; LIN_NOWQ(te); if (sid == 0) LIN_PUT(50, te); if (sid == S / 2) LIN_PUT(51, te); if (sid == S - 1) LIN_PUT(52, te); }
         const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
         const LinSlot sl(a.D, a.L, a.T);
         const int stride = max(sl.bytes, lin_scratch_bytes(NB));        // a slot doubles as the multiply's cross-wave scratch
@@ -815,6 +817,7 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) { 
             lin_barrier();
             LIN_NOWQ(s2);
             if (i >= 1 && t == 0 && !(a.diag & 4)) __hip_atomic_fetch_add(a.cnt_stream + item_batch(i - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i == 1) { [[maybe_unused]] unsigned long long te = 0; LIN_NOWQ(te); if (sid == 0) LIN_PUT(53, te); if (sid == S / 2) LIN_PUT(54, te); if (sid == S - 1) LIN_PUT(55, te); }
             const int n = item_batch(i), tile = item_tile(i);
             char* slot = lin_smem + (i & 1) * stride;
             lin_fix_tile(a, sl, tab[n], tab[kLinMaxPersist + n], tab[2 * kLinMaxPersist + n], tile, slot, t);
