@@ -179,3 +179,40 @@ def test_graph_replay_of_pipelined_steps_equals_the_eager_call():
     assert int(sg.item()) == int(se.item()) == 2 * n
     assert torch.equal(pg, pe) and torch.equal(mg, me) and torch.equal(vg, ve) and torch.equal(gg, ge)
     assert torch.equal(ring_g, ring_e) and float(ring_e[2 * n - 1]) < float(ring_e[0])
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_pipelined_steps_random_shapes(seed):
+    """Random (D, L, B, with / without the tunable decoder variance): odd row lengths (16-byte LDS-DMA pieces straddling rows and
+    tensor ends), fewer rows than a tile, three- and four-block feature counts (persistent and launch-per-step forms), batches
+    that need taller tiles -- three steps against the oracle each."""
+    rng = np.random.default_rng(1000 + seed)
+    while True:
+        D, L = int(rng.integers(1, 22)), int(rng.integers(1, 22))
+        if L + 2 * D + 1 <= 63:
+            break
+    B = int(rng.choice([1, 2, 7, 31, 255, 256, 257, 1000, 4097, 70001])) if seed < 10 else int(rng.integers(1, 3000))
+    if B * min(D, L) < 8:
+        B = 8
+    tdv = bool(rng.integers(0, 2))
+    cfg = O.Config(D, L, (), (), float(rng.uniform(-3.0, 0.5)), tdv, "linear_gaussian")
+    r32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    p = {k: r32(v) for k, v in O.init_params(cfg, seed=seed).items()}
+    for k in p:
+        if not k.endswith("kernel"):
+            p[k] = r32(p[k] + 0.2 * rng.standard_normal(p[k].shape))
+    n, lr = 3, 1e-3
+    A = rng.standard_normal((D, D)) / np.sqrt(D)
+    batches = []
+    for _ in range(n):
+        x = r32(rng.standard_normal((B, D)) @ A)
+        batches.append((x, r32(rng.standard_normal((B, L))), r32(rng.standard_normal((B, D)))))
+    eng = engine_for(cfg, B)
+    assert eng.supports_train_steps()
+    params, grads, m, v, step, losses = _run_pipelined(eng, cfg, p, batches, lr)
+    st = O.adam_init(p)
+    for i, (x, z1, z2) in enumerate(batches):
+        p, st, loss = O.train_step(cfg, p, st, x, z1, z2, lr)
+        assert abs(losses[i] - loss) <= 1e-5 * abs(loss) + 1e-6, (D, L, B, tdv, i, losses[i], loss)
+    assert step == n
+    assert np.max(np.abs(host(params) - O.flatten(cfg, p))) <= 0.02 * lr * n, (D, L, B, tdv)
