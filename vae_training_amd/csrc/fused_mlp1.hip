@@ -208,8 +208,10 @@ __global__ __launch_bounds__(M1_NT) void mlp1_fused_kernel(const Mlp1Args a) {
         M1_STAMP(2);
         // ---- encoder layer 1: HE[j][s] = relu(x[s] . We1[:, j] + be1[j])
         // (per group of 4 samples the broadcast operand rows are read into registers first, then used: hipcc otherwise waits out
-        // the LDS latency per product.  Reading the NEXT group's rows under the current group's arithmetic was tried in all four
-        // per-unit loops: the second register set spills -- 3 to 11 KB of scratch, 240 us per step.)
+        // the LDS latency per product.  Tried and backed out: reading the NEXT group's rows under the current group's arithmetic
+        // in all four per-unit loops -- the second register set spills, 3 to 11 KB of scratch, 240 us per step; and two threads
+        // per unit (512 threads, two waves per SIMD, each half of the samples) -- 256 registers per thread no longer hold the
+        // weights, the accumulators and the staged rows: 47 us per step against 33.)
 #pragma unroll 2
         for (int s4 = 0; s4 < M1_TS; s4 += 4) {
             float xr[4][DP];
