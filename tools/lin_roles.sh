@@ -1,8 +1,8 @@
 # Diagnostic: the persistent form of vaek_train_steps with some roles left out (VAEK_LIN_ROLES: 1 streamers only, 3 + reducers,
 # 7 everything), 64 steps of the metric's shape timed with events around the call.  Results are garbage unless ROLES=7.
 cd $GRAFT_REPO_ROOT
-for cfg in ${CFGS:-1:0 3:0 7:0}; do
-VAEK_LIN_ROLES=${cfg%%:*} VAEK_LIN_DIAG=${cfg##*:} python3 - <<'PY'
+for roles in 1 3 7; do
+VAEK_LIN_ROLES=$roles python3 - <<'PY'
 import sys, os
 sys.path.insert(0, os.getcwd())
 import torch
@@ -21,6 +21,6 @@ for it in range(4):
     e1.record()
     torch.cuda.synchronize()
     out.append(e0.elapsed_time(e1) * 1e3 / 64)
-print("roles", os.environ["VAEK_LIN_ROLES"], "diag", os.environ["VAEK_LIN_DIAG"], "rwg", os.environ.get("VAEK_LIN_RWG"), "us/step:", " ".join(f"{x:.2f}" for x in out))
+print("roles", os.environ["VAEK_LIN_ROLES"], "us/step:", " ".join(f"{x:.2f}" for x in out))
 PY
 done

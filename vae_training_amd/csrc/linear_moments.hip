@@ -73,7 +73,7 @@ struct LinArgs {
     const float* partial_in; double* M_out;                                       // [NBLK * 256]
     const double* M_in;
     // ---- persistent form: n_steps batches, pointer tables in device memory, one slot per batch, arrival counters
-    int persistent, n_steps, diag, sets;          // sets: reducer sets taking alternate batches
+    int persistent, n_steps, sets;                // sets: reducer sets taking alternate batches
     const float* const* xs; const float* const* z1s; const float* const* z2s;
     float* partial_base; double* M_base;                                          // slot n at + n * ntiles * NO resp. + n * NO
     unsigned* cnt_stream; unsigned* cnt_reduce; unsigned* status;                 // [n_steps], [n_steps], [1]; zeroed before the launch
@@ -767,15 +767,16 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) { 
             LIN_NOWQ(r0);
             lin_wait_count(a.cnt_stream + n, (unsigned)a.ntiles, a.status, (2u << 28) | ((unsigned)n << 16));
             LIN_NOWQ(r1);
-            if (!(a.diag & 1))
-                for (int sub = ro; sub < NO / 32; sub += 2 * per_set) {    // 32-output slices, two at a time where there are two (a 128-output
-                    if (sub != ro) __syncthreads();                     // form reading 16 bytes per lane with sc1 buffer loads measured 8 % SLOWER per step)
-                    const float* pin = a.partial_base + (long long)n * a.ntiles * NO;
-                    const unsigned epoch = (unsigned)(tstep0 + n + 1);      // the batch's Adam step: the tag of its exchange granules
-                    if (sub + per_set < NO / 32)
-                        lin_reduce_pair(pin, a.M_base + (long long)n * NO, a.ntiles, lin_smem, sub, sub + per_set, NO, a.comm, epoch, a.status);
-                    else lin_reduce<true>(pin, a.M_base + (long long)n * NO, a.ntiles, lin_smem, sub, NO, &a.comm, epoch, a.status);
-                }
+            // 32-output slices, two at a time where there are two (a 128-output form reading 16 bytes per lane with sc1 buffer loads
+            // measured 8 % SLOWER per step)
+            for (int sub = ro; sub < NO / 32; sub += 2 * per_set) {
+                if (sub != ro) __syncthreads();                         // the previous slices' LDS sums have been read
+                const float* pin = a.partial_base + (long long)n * a.ntiles * NO;
+                const unsigned epoch = (unsigned)(tstep0 + n + 1);          // the batch's Adam step: the tag of its exchange granules
+                if (sub + per_set < NO / 32)
+                    lin_reduce_pair(pin, a.M_base + (long long)n * NO, a.ntiles, lin_smem, sub, sub + per_set, NO, a.comm, epoch, a.status);
+                else lin_reduce<true>(pin, a.M_base + (long long)n * NO, a.ntiles, lin_smem, sub, NO, &a.comm, epoch, a.status);
+            }
             lin_wait_vmcnt<0>();                               // every storing wave drains its write-through stores ...
             __syncthreads();                                   // ... before the one lane that signals for the workgroup
             LIN_NOWQ(r2);
@@ -816,13 +817,13 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) { 
             // tile i has landed, and -- the counter retires in order -- so have this wave's write-through stores of item i - 1
             lin_barrier();
             LIN_NOWQ(s2);
-            if (i >= 1 && t == 0 && !(a.diag & 4)) __hip_atomic_fetch_add(a.cnt_stream + item_batch(i - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i >= 1 && t == 0) __hip_atomic_fetch_add(a.cnt_stream + item_batch(i - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (i == 1) { [[maybe_unused]] unsigned long long te = 0; LIN_NOWQ(te); if (sid == 0) LIN_PUT(53, te); if (sid == S / 2) LIN_PUT(54, te); if (sid == S - 1) LIN_PUT(55, te); }
             const int n = item_batch(i), tile = item_tile(i);
             char* slot = lin_smem + (i & 1) * stride;
             lin_fix_tile(a, sl, tab[n], tab[kLinMaxPersist + n], tab[2 * kLinMaxPersist + n], tile, slot, t);
             LIN_NOWQ(s3);
-            lin_multiply_tile<NB, true>(a, sl, slot, a.partial_base + ((long long)((a.diag & 2) ? 0 : n) * a.ntiles + tile) * NO, t, wave);
+            lin_multiply_tile<NB, true>(a, sl, slot, a.partial_base + ((long long)n * a.ntiles + tile) * NO, t, wave);
             lin_barrier();                                     // every wave's products are done: the slot is free for item i + 2
             LIN_NOWQ(s4);
             if (i + 1 < items) { sacc_i += s1 - s0; sacc_l += s2 - s1; sacc_f += s3 - s2; sacc_m += s4 - s3; }
@@ -971,12 +972,9 @@ int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v
             LinArgs a{};
             lin_fill_common(c, a, params, grads, m, v, step_dev, lr);
             a.persistent = 1; a.n_steps = n;
-            static const int rwg = getenv("VAEK_LIN_RWG") ? atoi(getenv("VAEK_LIN_RWG")) : kLinReduceWgs;     // diagnostic override
-            static const int sets = getenv("VAEK_LIN_SETS") ? atoi(getenv("VAEK_LIN_SETS")) : kLinReduceSets;    // diagnostic override
-            a.sets = sets;
-            a.has_update = 1; a.n_reduce = kLinReduceSets * std::min(rwg, no / 32); a.n_stream = lin_persist_streamers(c);
+            a.sets = kLinReduceSets;
+            a.has_update = 1; a.n_reduce = kLinReduceSets * std::min(kLinReduceWgs, no / 32); a.n_stream = lin_persist_streamers(c);
             static const int proles = getenv("VAEK_LIN_ROLES") ? atoi(getenv("VAEK_LIN_ROLES")) : 7;    // diagnostic (tools/lin_roles.sh)
-            a.diag = getenv("VAEK_LIN_DIAG") ? atoi(getenv("VAEK_LIN_DIAG")) : 0;
             if (!(proles & 4)) a.has_update = 0;
             if (!(proles & 2)) { a.has_update = 0; a.n_reduce = 0; }
             a.xs = txs; a.z1s = tz1; a.z2s = tz2;
