@@ -234,6 +234,14 @@ int vaek_train_steps(vaek_ctx* ctx, float* params, float* grads, float* m, float
  * (the results of that call are then invalid).  The word says which wait: 0x80000000 | role << 28 (1 the updater, 2 a reducer)
  * | batch index within the launch << 16 | the arrival count it last saw. */
 int vaek_train_steps_status(vaek_ctx* ctx, void* workspace, int32_t* gave_up);
+/* Convolutional VAE of BASELINE config 5 -- NO reference counterpart (the reference has no convolutional model: its only image
+ * code is utils.py:129-133); the layer is specified in DESIGN.md 3.4 and checked against oracle/conv_vae_oracle.py:conv_fwd.
+ * 4 x 4 / stride 2 / pad 1 convolution, NHWC float32 tensors, HWIO kernel [4][4][c_in][c_out], bf16 matrix-core products with
+ * float32 accumulation (the envelope of the bf16 Dense path, not the 1e-5 ELBO contract):
+ *   y[n, i, j, o] = act(bias[o] + sum_{kh, kw, c} x[n, 2 i + kh - 1, 2 j + kw - 1, c] * w[kh, kw, c, o]),  y: [batch, height/2, width/2, c_out].
+ * No context needed.  The transposed convolution and the gradients are not built yet. */
+int vaek_conv2d_forward(const float* x, const float* w, const float* bias, float* y, int32_t batch, int32_t height, int32_t width,
+                        int32_t c_in, int32_t c_out, int32_t relu, void* stream);
 /* n standard normals and/or the raw Philox words they came from (block b = counter (b_lo, b_hi, step, tag)). */
 int vaek_rng_fill(vaek_ctx* ctx, float* normals, uint32_t* bits, int64_t n, uint64_t seed, uint32_t step, uint32_t tag,
                   void* stream);

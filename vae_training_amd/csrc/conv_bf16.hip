@@ -1,0 +1,174 @@
+// Convolution layers of the convolutional VAE (BASELINE config 5; NO reference counterpart -- the architecture is this
+// repository's own specification, DESIGN.md 3.4, and oracle/conv_vae_oracle.py is what these kernels are checked against):
+// 4x4 / stride 2 / pad 1 convolutions on NHWC float32 tensors as IMPLICIT GEMMs on v_mfma_f32_32x32x16_bf16 (f32 accumulate,
+// operands rounded to bf16 while they are staged into LDS -- the arithmetic of gemm_bf16.hip, whose tile machinery this file
+// shares: 128 x 128 output tile, 4 waves x 2 x 2 MFMA tiles, 32-deep k-tiles, [row][k] LDS images at an 80-byte row stride,
+// next k-tile fetched into registers under the MFMAs).
+//
+//   forward   y[n, i, j, o] = act(b[o] + sum_{kh, kw, c} x[n, 2 i + kh - 1, 2 j + kw - 1, c] K[kh, kw, c, o])
+//             GEMM rows = output pixels (n, i, j), columns = o, inner index k = (kh, kw, c): the A operand is GATHERED from the
+//             input image (zeros outside it), never materialised; the HWIO kernel array IS the row-major [k][o] B operand;
+//             the row-major [pixel][o] result IS the NHWC output.
+//
+// Built so far: the forward convolution (the four encoder layers of config 5).  The transposed convolution / input gradient
+// (four parity-phase GEMMs with 2 x 2 taps each) and the kernel gradient (batch-split GEMM with the same gather transposed)
+// follow the same scheme and are not built yet.
+#include "vaek_internal.h"
+
+namespace vaek {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+
+constexpr int CBM = 128, CBN = 128, CNT = 256, CBK = 32, CSTR = CBK + 8, CKU = CBK / 8;
+
+struct ConvArgs {
+    const float* x; const float* w; const float* bias; float* y;
+    int B, H, W, Cin, Cout, Ho, Wo;
+    int M, N, K;                        // M = B Ho Wo, N = Cout, K = 16 Cin
+    int relu;
+};
+
+__global__ __launch_bounds__(CNT) void conv_fwd_kernel(const ConvArgs g) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[CBM * CSTR];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[CBN * CSTR];
+    const int m0 = blockIdx.y * CBM, n0 = blockIdx.x * CBN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- A operand: thread -> rows (t / 8) + 32 u, u < 4, and 4 consecutive k = k0 + 4 (t % 8) ..; the rows' pixels are fixed for
+    // the whole kernel: image base offset and the top-left input coordinate of the 4 x 4 window, decoded once
+    constexpr int TPR = CBK / 4, RPP = CNT / TPR;
+    long long a_img[CKU]; int a_y0[CKU], a_x0[CKU]; bool a_ok[CKU];
+#pragma unroll
+    for (int u = 0; u < CKU; ++u) {
+        const int row = m0 + t / TPR + RPP * u;
+        a_ok[u] = row < g.M;
+        const int rc = a_ok[u] ? row : 0, n = rc / (g.Ho * g.Wo), ij = rc % (g.Ho * g.Wo);
+        a_img[u] = (long long)n * g.H * g.W * g.Cin;
+        a_y0[u] = 2 * (ij / g.Wo) - 1; a_x0[u] = 2 * (ij % g.Wo) - 1;
+    }
+    const bool cin4 = g.Cin % 4 == 0 && (reinterpret_cast<uintptr_t>(g.x) & 15) == 0;
+    float ra[CKU][4], rb[CKU][4];
+    auto fetch_a = [&](int k0) {
+        const int k = k0 + (t % TPR) * 4;
+        if (cin4) {                                        // the 4 k share a tap and are 4 consecutive channels: one 16-byte load
+            const int tap = k / g.Cin, c = k % g.Cin, kh = tap >> 2, kw = tap & 3;
+#pragma unroll
+            for (int u = 0; u < CKU; ++u) {                // unconditional at a clamped address, selected afterwards
+                const int yy = a_y0[u] + kh, xx = a_x0[u] + kw;
+                const bool in = a_ok[u] && k < g.K && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+                const int yc = min(max(yy, 0), g.H - 1), xc = min(max(xx, 0), g.W - 1), cc = min(c, g.Cin - 4);
+                const float4 f = *reinterpret_cast<const float4*>(g.x + a_img[u] + ((long long)yc * g.W + xc) * g.Cin + cc);
+                ra[u][0] = in ? f.x : 0.f; ra[u][1] = in ? f.y : 0.f; ra[u][2] = in ? f.z : 0.f; ra[u][3] = in ? f.w : 0.f;
+            }
+        } else {                                           // any channel count (the first layer: 1 channel, K = 16)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ke = min(k + e, g.K - 1), tap = ke / g.Cin, c = ke % g.Cin, kh = tap >> 2, kw = tap & 3;
+#pragma unroll
+                for (int u = 0; u < CKU; ++u) {
+                    const int yy = a_y0[u] + kh, xx = a_x0[u] + kw;
+                    const bool in = a_ok[u] && k + e < g.K && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+                    const int yc = min(max(yy, 0), g.H - 1), xc = min(max(xx, 0), g.W - 1);
+                    const float f = g.x[a_img[u] + ((long long)yc * g.W + xc) * g.Cin + c];
+                    ra[u][e] = in ? f : 0.f;
+                }
+            }
+        }
+    };
+    // ---- B operand: the HWIO kernel array as [k][o]: thread -> ONE column o = n0 + (t & 127) and 16 consecutive k (gemm_bf16.hip)
+    auto fetch_b = [&](int k0) {
+        const int col = n0 + (t & 127), kb = k0 + (CBK / 2) * (t >> 7), colc = min(col, g.N - 1);
+#pragma unroll
+        for (int u = 0; u < CKU; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k = kb + 4 * u + c;
+                const float f = g.w[(long long)min(k, g.K - 1) * g.N + colc];
+                rb[u][c] = (k < g.K && col < g.N) ? f : 0.f;
+            }
+    };
+    fetch_a(0); fetch_b(0);
+    for (int k0 = 0; k0 < g.K; k0 += CBK) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < CKU; ++u) {
+            const bf16x4 h = {(__bf16)ra[u][0], (__bf16)ra[u][1], (__bf16)ra[u][2], (__bf16)ra[u][3]};
+            *reinterpret_cast<bf16x4*>(&As[(t / TPR + RPP * u) * CSTR + (t % TPR) * 4]) = h;
+        }
+        {
+            __bf16* rowp = Bs + (t & 127) * CSTR + (CBK / 2) * (t >> 7);
+#pragma unroll
+            for (int h = 0; h < CKU / 2; ++h) {
+                const bf16x8 w8 = {(__bf16)rb[2 * h][0], (__bf16)rb[2 * h][1], (__bf16)rb[2 * h][2], (__bf16)rb[2 * h][3],
+                                   (__bf16)rb[2 * h + 1][0], (__bf16)rb[2 * h + 1][1], (__bf16)rb[2 * h + 1][2], (__bf16)rb[2 * h + 1][3]};
+                *reinterpret_cast<bf16x8*>(rowp + 8 * h) = w8;
+            }
+        }
+        __syncthreads();
+        if (k0 + CBK < g.K) { fetch_a(k0 + CBK); fetch_b(k0 + CBK); }
+        // fragments: lane (row = lane & 31, half = lane >> 5) holds k = 16 s + 8 half .. + 7 of its row
+        const __bf16* pa = As + (wm * 64 + (lane & 31)) * CSTR + 8 * (lane >> 5);
+        const __bf16* pb = Bs + (wn * 64 + (lane & 31)) * CSTR + 8 * (lane >> 5);
+#pragma unroll
+        for (int s = 0; s < CBK / 16; ++s) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(pa + i * 32 * CSTR + 16 * s);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * CSTR + 16 * s);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: bias, relu; the [pixel][o] tile is the NHWC output
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (col >= g.N) continue;
+        const float bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= g.M) continue;
+                float v = acc[i][j][r] + bias;
+                if (g.relu) v = fmaxf(v, 0.f);
+                g.y[(long long)row * g.N + col] = v;
+            }
+    }
+}
+
+}  // namespace vaek
+
+using namespace vaek;
+
+extern "C" int vaek_conv2d_forward(const float* x, const float* w, const float* bias, float* y, int32_t batch, int32_t height,
+                                   int32_t width, int32_t c_in, int32_t c_out, int32_t relu, void* stream) {
+    if (!x || !w || !y || batch < 1 || height < 2 || width < 2 || (height & 1) || (width & 1) || c_in < 1 || c_out < 1) {
+        set_error("vaek_conv2d_forward: invalid argument");
+        return VAEK_ERR_INVALID;
+    }
+    ConvArgs g{};
+    g.x = x; g.w = w; g.bias = bias; g.y = y;
+    g.B = batch; g.H = height; g.W = width; g.Cin = c_in; g.Cout = c_out; g.Ho = height / 2; g.Wo = width / 2;
+    const long long M = (long long)batch * g.Ho * g.Wo;
+    if (M > 0x7fffffffll || (M + CBM - 1) / CBM > 65535) { set_error("vaek_conv2d_forward: too many output pixels"); return VAEK_ERR_INVALID; }
+    g.M = (int)M; g.N = c_out; g.K = 16 * c_in; g.relu = relu;
+    ProfScope ps("conv_fwd_bf16", (hipStream_t)stream);
+    launch_k(ps, conv_fwd_kernel, dim3((g.N + CBN - 1) / CBN, (g.M + CBM - 1) / CBM), dim3(CNT), 0, (hipStream_t)stream, g);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
