@@ -48,3 +48,42 @@ def test_conv2d_forward_rejects_odd_sizes():
     from vae_training_amd.conv import conv2d_forward
     with pytest.raises(VaekError):
         conv2d_forward(torch.zeros(1, 5, 5, 4, device="cuda"), torch.zeros(4, 4, 4, 8, device="cuda"))
+
+
+@pytest.mark.parametrize("B,h,cin,cout,relu,masked", [
+    (8, 4, 256, 128, True, False),     # the four decoder layers of config 5
+    (8, 8, 128, 64, True, False),
+    (8, 16, 64, 32, True, False),
+    (8, 32, 32, 1, False, False),
+    (3, 5, 4, 5, False, True),         # odd sizes, ragged rows and columns, the input-gradient form with a relu mask
+    (2, 3, 3, 7, True, False),         # channel count off the 4-grid: the scalar gathers
+    (1, 1, 8, 130, False, True),       # one input pixel; more than one column tile
+])
+def test_conv2d_transpose_forward_matches_the_oracle(B, h, cin, cout, relu, masked):
+    from vae_training_amd.conv import conv2d_transpose_forward
+    rng = np.random.default_rng(B * 1000 + h + cin)
+    r32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    y = r32(rng.standard_normal((B, h, h, cin)))
+    w = r32(rng.standard_normal((4, 4, cout, cin)) / np.sqrt(4 * cin))
+    b = r32(0.1 * rng.standard_normal(cout))
+    want = CO.conv_t_fwd(y, w, b)
+    if relu:
+        want = np.maximum(want, 0.0)
+    mask = r32(rng.standard_normal(want.shape)) if masked else None
+    if masked:
+        want = want * (mask > 0.0)
+    got = conv2d_transpose_forward(_dev(y), _dev(w), _dev(b), relu, None if mask is None else _dev(mask)).cpu().numpy().astype(np.float64)
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) / np.max(np.abs(want)) <= 1e-2
+
+
+def test_transposed_kernel_is_the_adjoint_of_the_forward_kernel():
+    """<conv(x), y> == <x, conv_t(y)> for the two HIP kernels themselves (bf16 products: to 1e-2 of the inner product's scale)."""
+    from vae_training_amd.conv import conv2d_forward, conv2d_transpose_forward
+    torch.manual_seed(0)
+    x = torch.randn(4, 16, 16, 8, device="cuda"); K = torch.randn(4, 4, 8, 12, device="cuda") / 11.3
+    y = torch.randn(4, 8, 8, 12, device="cuda")
+    lhs = float((conv2d_forward(x, K).double() * y.double()).sum())
+    rhs = float((x.double() * conv2d_transpose_forward(y, K).double()).sum())
+    scale = float(conv2d_forward(x, K).double().norm() * y.double().norm())
+    assert abs(lhs - rhs) <= 1e-2 * scale, (lhs, rhs, scale)

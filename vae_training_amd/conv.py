@@ -20,3 +20,20 @@ def conv2d_forward(x, w, bias=None, relu=False):
     _lib.check(lib.vaek_conv2d_forward(p(x), p(w), p(bias), p(y), B, H, W, Cin, Cout, int(bool(relu)),
                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     return y
+
+
+def conv2d_transpose_forward(y, w, bias=None, relu=False, mask=None):
+    """The adjoint of conv2d_forward with the same kernel array: y [B, h, w, Cin], w [4, 4, Cout, Cin] -> [B, 2 h, 2 w, Cout]
+    (vaek_conv2d_transpose_forward).  With bias=None it is the convolution's input gradient; `mask` applies the relu of the layer
+    below ([mask > 0])."""
+    lib = _lib.load()
+    assert y.is_cuda and w.is_cuda and y.dtype == w.dtype == torch.float32 and y.is_contiguous() and w.is_contiguous()
+    B, h, wd, Cin = y.shape
+    assert tuple(w.shape[:2]) == (4, 4) and w.shape[3] == Cin
+    Cout = w.shape[2]
+    out = torch.empty(B, 2 * h, 2 * wd, Cout, dtype=torch.float32, device=y.device)
+    assert mask is None or (mask.shape == out.shape and mask.is_contiguous())
+    p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
+    _lib.check(lib.vaek_conv2d_transpose_forward(p(y), p(w), p(bias), p(mask), p(out), B, h, wd, Cin, Cout, int(bool(relu)),
+                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return out

@@ -10,9 +10,9 @@
 //             input image (zeros outside it), never materialised; the HWIO kernel array IS the row-major [k][o] B operand;
 //             the row-major [pixel][o] result IS the NHWC output.
 //
-// Built so far: the forward convolution (the four encoder layers of config 5).  The transposed convolution / input gradient
-// (four parity-phase GEMMs with 2 x 2 taps each) and the kernel gradient (batch-split GEMM with the same gather transposed)
-// follow the same scheme and are not built yet.
+// Built so far: the forward convolution (the four encoder layers of config 5) and the transposed convolution = the input gradient
+// (four parity-phase GEMMs with 2 x 2 taps each, below).  The kernel gradient (batch-split GEMM with the gather transposed) is
+// not built yet.
 #include "vaek_internal.h"
 
 namespace vaek {
@@ -29,6 +29,56 @@ struct ConvArgs {
     int M, N, K;                        // M = B Ho Wo, N = Cout, K = 16 Cin
     int relu;
 };
+
+// The shared main loop: registers -> LDS (A: thread = row t / 8 + 32 u, 4 consecutive k; B either the same form, B_KCONT, or
+// thread = column t & 127, 16 consecutive k), barrier, next k-tile's fetch into registers, 2 x 2 MFMA tiles per wave.
+template <bool B_KCONT, typename FA, typename FB>
+__device__ __forceinline__ void conv_mainloop(__bf16* As, __bf16* Bs, int K, float (&ra)[CKU][4], float (&rb)[CKU][4], FA fetch_a,
+                                              FB fetch_b, f32x16 (&acc)[2][2]) {
+    constexpr int TPR = CBK / 4, RPP = CNT / TPR;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    fetch_a(0); fetch_b(0);
+    for (int k0 = 0; k0 < K; k0 += CBK) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < CKU; ++u) {
+            const bf16x4 h = {(__bf16)ra[u][0], (__bf16)ra[u][1], (__bf16)ra[u][2], (__bf16)ra[u][3]};
+            *reinterpret_cast<bf16x4*>(&As[(t / TPR + RPP * u) * CSTR + (t % TPR) * 4]) = h;
+        }
+        if (B_KCONT) {
+#pragma unroll
+            for (int u = 0; u < CKU; ++u) {
+                const bf16x4 h = {(__bf16)rb[u][0], (__bf16)rb[u][1], (__bf16)rb[u][2], (__bf16)rb[u][3]};
+                *reinterpret_cast<bf16x4*>(&Bs[(t / TPR + RPP * u) * CSTR + (t % TPR) * 4]) = h;
+            }
+        } else {
+            __bf16* rowp = Bs + (t & 127) * CSTR + (CBK / 2) * (t >> 7);
+#pragma unroll
+            for (int h = 0; h < CKU / 2; ++h) {
+                const bf16x8 w8 = {(__bf16)rb[2 * h][0], (__bf16)rb[2 * h][1], (__bf16)rb[2 * h][2], (__bf16)rb[2 * h][3],
+                                   (__bf16)rb[2 * h + 1][0], (__bf16)rb[2 * h + 1][1], (__bf16)rb[2 * h + 1][2], (__bf16)rb[2 * h + 1][3]};
+                *reinterpret_cast<bf16x8*>(rowp + 8 * h) = w8;
+            }
+        }
+        __syncthreads();
+        if (k0 + CBK < K) { fetch_a(k0 + CBK); fetch_b(k0 + CBK); }
+        // fragments: lane (row = lane & 31, half = lane >> 5) holds k = 16 s + 8 half .. + 7 of its row
+        const __bf16* pa = As + (wm * 64 + (lane & 31)) * CSTR + 8 * (lane >> 5);
+        const __bf16* pb = Bs + (wn * 64 + (lane & 31)) * CSTR + 8 * (lane >> 5);
+#pragma unroll
+        for (int s = 0; s < CBK / 16; ++s) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(pa + i * 32 * CSTR + 16 * s);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * CSTR + 16 * s);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+}
 
 __global__ __launch_bounds__(CNT) void conv_fwd_kernel(const ConvArgs g) {
     __shared__ __attribute__((aligned(16))) __bf16 As[CBM * CSTR];
@@ -97,41 +147,7 @@ __global__ __launch_bounds__(CNT) void conv_fwd_kernel(const ConvArgs g) {
                 rb[u][c] = (k < g.K && col < g.N) ? f : 0.f;
             }
     };
-    fetch_a(0); fetch_b(0);
-    for (int k0 = 0; k0 < g.K; k0 += CBK) {
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < CKU; ++u) {
-            const bf16x4 h = {(__bf16)ra[u][0], (__bf16)ra[u][1], (__bf16)ra[u][2], (__bf16)ra[u][3]};
-            *reinterpret_cast<bf16x4*>(&As[(t / TPR + RPP * u) * CSTR + (t % TPR) * 4]) = h;
-        }
-        {
-            __bf16* rowp = Bs + (t & 127) * CSTR + (CBK / 2) * (t >> 7);
-#pragma unroll
-            for (int h = 0; h < CKU / 2; ++h) {
-                const bf16x8 w8 = {(__bf16)rb[2 * h][0], (__bf16)rb[2 * h][1], (__bf16)rb[2 * h][2], (__bf16)rb[2 * h][3],
-                                   (__bf16)rb[2 * h + 1][0], (__bf16)rb[2 * h + 1][1], (__bf16)rb[2 * h + 1][2], (__bf16)rb[2 * h + 1][3]};
-                *reinterpret_cast<bf16x8*>(rowp + 8 * h) = w8;
-            }
-        }
-        __syncthreads();
-        if (k0 + CBK < g.K) { fetch_a(k0 + CBK); fetch_b(k0 + CBK); }
-        // fragments: lane (row = lane & 31, half = lane >> 5) holds k = 16 s + 8 half .. + 7 of its row
-        const __bf16* pa = As + (wm * 64 + (lane & 31)) * CSTR + 8 * (lane >> 5);
-        const __bf16* pb = Bs + (wn * 64 + (lane & 31)) * CSTR + 8 * (lane >> 5);
-#pragma unroll
-        for (int s = 0; s < CBK / 16; ++s) {
-            bf16x8 fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(pa + i * 32 * CSTR + 16 * s);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * CSTR + 16 * s);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-    }
+    conv_mainloop<false>(As, Bs, g.K, ra, rb, fetch_a, fetch_b, acc);
     // ---- epilogue: bias, relu; the [pixel][o] tile is the NHWC output
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -151,9 +167,156 @@ __global__ __launch_bounds__(CNT) void conv_fwd_kernel(const ConvArgs g) {
     }
 }
 
+// ---- transposed convolution = the adjoint of the convolution above with the same kernel array ------------------------------------
+//   out[n, P, Q, o] = act(b[o] + sum_{kh, kw, c : (P + 1 - kh), (Q + 1 - kw) even} y[n, (P + 1 - kh) / 2, (Q + 1 - kw) / 2, c] K[kh, kw, o, c])
+// (K [4, 4, C_out, C_in]: the HWIO kernel of the convolution it is the adjoint of; oracle: conv_t_fwd.)  For an output pixel of
+// parity (pp, qq) = (P % 2, Q % 2) exactly 2 x 2 taps contribute: kh = 1 - pp + 2 th reads input row P' + pp - th (P = 2 P' + pp),
+// likewise in x.  So the layer is FOUR GEMMs, one per parity class (blockIdx.z): rows = (n, P', Q'), inner index k = (th, tw, c),
+// 4 C_in deep, the A operand gathered from y, the B operand the class's four [o][c] slices of K (k-contiguous: the row form of
+// the loader), the result scattered to the class's pixels.  The same kernel is the convolution's INPUT GRADIENT (y := dL/d out
+// of the convolution, no bias; `mask`: multiply by [mask > 0], the relu of the layer below).
+struct ConvTArgs {
+    const float* y; const float* w; const float* bias; const float* mask; float* out;
+    int B, h, w_in, Cin, Cout;          // input [B, h, w_in, Cin] -> output [B, 2 h, 2 w_in, Cout]
+    int M, N, K;                        // per parity class: M = B h w_in, N = Cout, K = 4 Cin
+    int relu;
+};
+
+__global__ __launch_bounds__(CNT) void conv_t_fwd_kernel(const ConvTArgs g) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[CBM * CSTR];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[CBN * CSTR];
+    __shared__ long long rowoff[CBM];                      // output offset of the tile's rows (-1: past the end)
+    const int m0 = blockIdx.y * CBM, n0 = blockIdx.x * CBN, pp = blockIdx.z >> 1, qq = blockIdx.z & 1;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (t < CBM) {
+        const int row = m0 + t;
+        long long off = -1;
+        if (row < g.M) {
+            const int n = row / (g.h * g.w_in), ij = row % (g.h * g.w_in), P = 2 * (ij / g.w_in) + pp, Q = 2 * (ij % g.w_in) + qq;
+            off = (((long long)n * 2 * g.h + P) * 2 * g.w_in + Q) * g.Cout;
+        }
+        rowoff[t] = off;
+    }
+    constexpr int TPR = CBK / 4, RPP = CNT / TPR;
+    long long a_img[CKU]; int a_i[CKU], a_j[CKU]; bool a_ok[CKU];
+#pragma unroll
+    for (int u = 0; u < CKU; ++u) {
+        const int row = m0 + t / TPR + RPP * u;
+        a_ok[u] = row < g.M;
+        const int rc = a_ok[u] ? row : 0, n = rc / (g.h * g.w_in), ij = rc % (g.h * g.w_in);
+        a_img[u] = (long long)n * g.h * g.w_in * g.Cin;
+        a_i[u] = ij / g.w_in + pp; a_j[u] = ij % g.w_in + qq;         // input pixel = (a_i - th, a_j - tw)
+    }
+    const bool c4 = g.Cin % 4 == 0 && (reinterpret_cast<uintptr_t>(g.y) & 15) == 0 && (reinterpret_cast<uintptr_t>(g.w) & 15) == 0;
+    float ra[CKU][4], rb[CKU][4];
+    auto fetch_a = [&](int k0) {
+        const int k = k0 + (t % TPR) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; e += 4) {
+            if (c4) {
+                const int tap = min(k / g.Cin, 3), c = k % g.Cin, th = tap >> 1, tw = tap & 1;
+#pragma unroll
+                for (int u = 0; u < CKU; ++u) {            // unconditional at a clamped address, selected afterwards
+                    const int yy = a_i[u] - th, xx = a_j[u] - tw;
+                    const bool in = a_ok[u] && k < g.K && yy >= 0 && yy < g.h && xx >= 0 && xx < g.w_in;
+                    const int yc = min(max(yy, 0), g.h - 1), xc = min(max(xx, 0), g.w_in - 1);
+                    const float4 f = *reinterpret_cast<const float4*>(g.y + a_img[u] + ((long long)yc * g.w_in + xc) * g.Cin + c);
+                    ra[u][0] = in ? f.x : 0.f; ra[u][1] = in ? f.y : 0.f; ra[u][2] = in ? f.z : 0.f; ra[u][3] = in ? f.w : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int ee = 0; ee < 4; ++ee) {
+                    const int ke = min(k + ee, g.K - 1), tap = ke / g.Cin, c = ke % g.Cin, th = tap >> 1, tw = tap & 1;
+#pragma unroll
+                    for (int u = 0; u < CKU; ++u) {
+                        const int yy = a_i[u] - th, xx = a_j[u] - tw;
+                        const bool in = a_ok[u] && k + ee < g.K && yy >= 0 && yy < g.h && xx >= 0 && xx < g.w_in;
+                        const int yc = min(max(yy, 0), g.h - 1), xc = min(max(xx, 0), g.w_in - 1);
+                        const float f = g.y[a_img[u] + ((long long)yc * g.w_in + xc) * g.Cin + c];
+                        ra[u][ee] = in ? f : 0.f;
+                    }
+                }
+            }
+        }
+    };
+    // B operand, row form: thread -> output channels o = n0 + t / 8 + 32 u and 4 consecutive k of tap (th, tw): K[kh, kw, o, c ..]
+    auto fetch_b = [&](int k0) {
+        const int k = k0 + (t % TPR) * 4;
+        if (c4) {
+            const int tap = min(k / g.Cin, 3), c = k % g.Cin, kh = 1 - pp + 2 * (tap >> 1), kw = 1 - qq + 2 * (tap & 1);
+            const float* base = g.w + (long long)(kh * 4 + kw) * g.Cout * g.Cin + c;
+#pragma unroll
+            for (int u = 0; u < CKU; ++u) {
+                const int o = n0 + t / TPR + RPP * u;
+                const float4 f = *reinterpret_cast<const float4*>(base + (long long)min(o, g.N - 1) * g.Cin);
+                const bool in = o < g.N && k < g.K;
+                rb[u][0] = in ? f.x : 0.f; rb[u][1] = in ? f.y : 0.f; rb[u][2] = in ? f.z : 0.f; rb[u][3] = in ? f.w : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) {
+                const int ke = min(k + ee, g.K - 1), tap = ke / g.Cin, c = ke % g.Cin, kh = 1 - pp + 2 * (tap >> 1), kw = 1 - qq + 2 * (tap & 1);
+                const float* base = g.w + (long long)(kh * 4 + kw) * g.Cout * g.Cin + c;
+#pragma unroll
+                for (int u = 0; u < CKU; ++u) {
+                    const int o = n0 + t / TPR + RPP * u;
+                    const float f = base[(long long)min(o, g.N - 1) * g.Cin];
+                    rb[u][ee] = (o < g.N && k + ee < g.K) ? f : 0.f;
+                }
+            }
+        }
+    };
+    conv_mainloop<true>(As, Bs, g.K, ra, rb, fetch_a, fetch_b, acc);
+    // (rowoff was written before the main loop's first barrier)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (col >= g.N) continue;
+        const float bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long off = rowoff[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+                if (off < 0) continue;
+                float v = acc[i][j][r] + bias;
+                if (g.relu) v = fmaxf(v, 0.f);
+                if (g.mask) v = g.mask[off + col] > 0.f ? v : 0.f;
+                g.out[off + col] = v;
+            }
+    }
+}
+
 }  // namespace vaek
 
 using namespace vaek;
+
+extern "C" int vaek_conv2d_transpose_forward(const float* y, const float* w, const float* bias, const float* mask, float* out,
+                                             int32_t batch, int32_t height, int32_t width, int32_t c_in, int32_t c_out, int32_t relu,
+                                             void* stream) {
+    if (!y || !w || !out || batch < 1 || height < 1 || width < 1 || c_in < 1 || c_out < 1) {
+        set_error("vaek_conv2d_transpose_forward: invalid argument");
+        return VAEK_ERR_INVALID;
+    }
+    ConvTArgs g{};
+    g.y = y; g.w = w; g.bias = bias; g.mask = mask; g.out = out;
+    g.B = batch; g.h = height; g.w_in = width; g.Cin = c_in; g.Cout = c_out;
+    const long long M = (long long)batch * height * width;
+    if (M > 0x7fffffffll || (M + CBM - 1) / CBM > 65535) { set_error("vaek_conv2d_transpose_forward: too many pixels"); return VAEK_ERR_INVALID; }
+    g.M = (int)M; g.N = c_out; g.K = 4 * c_in; g.relu = relu;
+    ProfScope ps("conv_t_fwd_bf16", (hipStream_t)stream);
+    launch_k(ps, conv_t_fwd_kernel, dim3((g.N + CBN - 1) / CBN, (g.M + CBM - 1) / CBM, 4), dim3(CNT), 0, (hipStream_t)stream, g);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
 
 extern "C" int vaek_conv2d_forward(const float* x, const float* w, const float* bias, float* y, int32_t batch, int32_t height,
                                    int32_t width, int32_t c_in, int32_t c_out, int32_t relu, void* stream) {
