@@ -239,7 +239,8 @@ int vaek_train_steps_status(vaek_ctx* ctx, void* workspace, int32_t* gave_up);
  * 4 x 4 / stride 2 / pad 1 convolution, NHWC float32 tensors, HWIO kernel [4][4][c_in][c_out], bf16 matrix-core products with
  * float32 accumulation (the envelope of the bf16 Dense path, not the 1e-5 ELBO contract):
  *   y[n, i, j, o] = act(bias[o] + sum_{kh, kw, c} x[n, 2 i + kh - 1, 2 j + kw - 1, c] * w[kh, kw, c, o]),  y: [batch, height/2, width/2, c_out].
- * No context needed.  The kernel gradient is not built yet. */
+ * No context needed.  With the two entry points below every product of both layer kinds' forward and backward passes exists; the
+ * convolutional VAE's train step is not assembled yet. */
 int vaek_conv2d_forward(const float* x, const float* w, const float* bias, float* y, int32_t batch, int32_t height, int32_t width,
                         int32_t c_in, int32_t c_out, int32_t relu, void* stream);
 /* The transposed convolution of the same specification = the adjoint of vaek_conv2d_forward with the SAME kernel array
@@ -248,6 +249,13 @@ int vaek_conv2d_forward(const float* x, const float* w, const float* bias, float
  * NULL); `mask` (NULL or a tensor of out's shape) multiplies the result by [mask > 0] -- the relu of the layer below. */
 int vaek_conv2d_transpose_forward(const float* y, const float* w, const float* bias, const float* mask, float* out, int32_t batch,
                                   int32_t height, int32_t width, int32_t c_in, int32_t c_out, int32_t relu, void* stream);
+/* Kernel gradient of vaek_conv2d_forward (oracle: conv_bwd): dw[kh, kw, c, o] = sum_{n, i, j} x[n, 2 i + kh - 1, 2 j + kw - 1, c] *
+ * dy[n, i, j, o], dbias[o] = sum dy (NULL: not wanted); x [batch, height, width, c_in], dy [batch, height/2, width/2, c_out].
+ * Batch-split slabs in `workspace` (vaek_conv2d_weight_grad_workspace bytes) + a fixed-order sum: bitwise repeatable.  With
+ * (x := dL/d out, dy := the layer's input) it is the TRANSPOSED layer's kernel gradient in its [4][4][c_out][c_in] layout. */
+int vaek_conv2d_weight_grad_workspace(int32_t batch, int32_t height, int32_t width, int32_t c_in, int32_t c_out, size_t* bytes);
+int vaek_conv2d_weight_grad(const float* x, const float* dy, float* dw, float* dbias, void* workspace, int32_t batch, int32_t height,
+                            int32_t width, int32_t c_in, int32_t c_out, void* stream);
 /* n standard normals and/or the raw Philox words they came from (block b = counter (b_lo, b_hi, step, tag)). */
 int vaek_rng_fill(vaek_ctx* ctx, float* normals, uint32_t* bits, int64_t n, uint64_t seed, uint32_t step, uint32_t tag,
                   void* stream);

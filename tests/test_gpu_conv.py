@@ -87,3 +87,38 @@ def test_transposed_kernel_is_the_adjoint_of_the_forward_kernel():
     rhs = float((x.double() * conv2d_transpose_forward(y, K).double()).sum())
     scale = float(conv2d_forward(x, K).double().norm() * y.double().norm())
     assert abs(lhs - rhs) <= 1e-2 * scale, (lhs, rhs, scale)
+
+
+@pytest.mark.parametrize("B,S,cin,cout", [
+    (8, 64, 1, 32), (8, 32, 32, 64), (8, 16, 64, 128), (8, 8, 128, 256),       # the four encoder layers of config 5
+    (3, 16, 4, 5), (2, 6, 3, 7), (1, 2, 8, 130), (37, 8, 12, 16),
+])
+def test_conv2d_weight_grad_matches_the_oracle(B, S, cin, cout):
+    from vae_training_amd.conv import conv2d_weight_grad
+    rng = np.random.default_rng(B * 1000 + S + cin + 7)
+    r32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    x = r32(rng.standard_normal((B, S, S, cin)))
+    dy = r32(rng.standard_normal((B, S // 2, S // 2, cout)))
+    _, want_w, want_b = CO.conv_bwd(x, np.zeros((4, 4, cin, cout)), dy)
+    dw, db = conv2d_weight_grad(_dev(x), _dev(dy))
+    dw2, db2 = conv2d_weight_grad(_dev(x), _dev(dy))
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)                     # slabs + fixed-order sum: bitwise repeatable
+    dw, db = dw.cpu().numpy().astype(np.float64), db.cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(dw - want_w)) <= 1e-2 * np.max(np.abs(want_w))
+    assert np.max(np.abs(db - want_b)) <= 1e-2 * np.max(np.abs(want_b))
+
+
+def test_transposed_layer_backward_from_the_same_three_kernels():
+    """conv_t_bwd of the oracle (d input, d kernel, d bias of the transposed layer) assembled from the HIP kernels:
+    d input = conv2d_forward(d out, K), d kernel = conv2d_weight_grad(x := d out, dy := input) in the [4, 4, C_out, C_in] layout."""
+    from vae_training_amd.conv import conv2d_forward, conv2d_weight_grad
+    rng = np.random.default_rng(5)
+    r32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    B, h, cin, cout = 4, 8, 16, 12
+    y = r32(rng.standard_normal((B, h, h, cin))); K = r32(rng.standard_normal((4, 4, cout, cin)) / 8.0)
+    dout = r32(rng.standard_normal((B, 2 * h, 2 * h, cout)))
+    want_dy, want_dK, want_db = CO.conv_t_bwd(y, K, dout)
+    got_dy = conv2d_forward(_dev(dout), _dev(K)).cpu().numpy().astype(np.float64)
+    got_dK = conv2d_weight_grad(_dev(dout), _dev(y), want_bias=False)[0].cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(got_dy - want_dy)) <= 1e-2 * np.max(np.abs(want_dy))
+    assert got_dK.shape == want_dK.shape and np.max(np.abs(got_dK - want_dK)) <= 1e-2 * np.max(np.abs(want_dK))

@@ -72,6 +72,8 @@ SIGNATURES = {
     "vaek_train_steps_status": (C.c_int, [_vp, _vp, C.POINTER(_i32)]),
     "vaek_conv2d_forward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vaek_conv2d_transpose_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vaek_conv2d_weight_grad_workspace": (C.c_int, [_i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_size_t)]),
+    "vaek_conv2d_weight_grad": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vaek_rng_fill": (C.c_int, [_vp, _vp, _vp, _i64, C.c_uint64, C.c_uint32, C.c_uint32, _vp]),
     "vaek_set_loss_history": (C.c_int, [_vp, _vp, _i64]),
     "vaek_microbench_copy": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),

@@ -37,3 +37,22 @@ def conv2d_transpose_forward(y, w, bias=None, relu=False, mask=None):
     _lib.check(lib.vaek_conv2d_transpose_forward(p(y), p(w), p(bias), p(mask), p(out), B, h, wd, Cin, Cout, int(bool(relu)),
                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     return out
+
+
+def conv2d_weight_grad(x, dy, want_bias=True):
+    """Kernel (and bias) gradient of conv2d_forward: x [B, H, W, Cin], dy [B, H/2, W/2, Cout] -> (dw [4, 4, Cin, Cout], db [Cout] or None)
+    (vaek_conv2d_weight_grad: batch-split implicit GEMM + fixed-order slab sum)."""
+    lib = _lib.load()
+    assert x.is_cuda and dy.is_cuda and x.dtype == dy.dtype == torch.float32 and x.is_contiguous() and dy.is_contiguous()
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    assert tuple(dy.shape[:3]) == (B, H // 2, W // 2)
+    nbytes = C.c_size_t()
+    _lib.check(lib.vaek_conv2d_weight_grad_workspace(B, H, W, Cin, Cout, C.byref(nbytes)))
+    ws = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=x.device)
+    dw = torch.empty(4, 4, Cin, Cout, dtype=torch.float32, device=x.device)
+    db = torch.empty(Cout, dtype=torch.float32, device=x.device) if want_bias else None
+    p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
+    _lib.check(lib.vaek_conv2d_weight_grad(p(x), p(dy), p(dw), p(db), p(ws), B, H, W, Cin, Cout,
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return dw, db

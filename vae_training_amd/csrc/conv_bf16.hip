@@ -11,8 +11,9 @@
 //             the row-major [pixel][o] result IS the NHWC output.
 //
 // Built so far: the forward convolution (the four encoder layers of config 5) and the transposed convolution = the input gradient
-// (four parity-phase GEMMs with 2 x 2 taps each, below).  The kernel gradient (batch-split GEMM with the gather transposed) is
-// not built yet.
+// (four parity-phase GEMMs with 2 x 2 taps each) and the kernel gradient (batch-split GEMM with the gather transposed): every
+// product of both layer kinds' forward and backward passes (oracle: conv_fwd / conv_bwd / conv_t_fwd / conv_t_bwd).  The
+// convolutional VAE's train step (bottleneck Dense layers + ELBO around them) is not assembled yet.
 #include "vaek_internal.h"
 
 namespace vaek {
@@ -32,18 +33,28 @@ struct ConvArgs {
 
 // The shared main loop: registers -> LDS (A: thread = row t / 8 + 32 u, 4 consecutive k; B either the same form, B_KCONT, or
 // thread = column t & 127, 16 consecutive k), barrier, next k-tile's fetch into registers, 2 x 2 MFMA tiles per wave.
-template <bool B_KCONT, typename FA, typename FB>
+template <bool B_KCONT, bool A_KCONT = true, typename FA, typename FB>
 __device__ __forceinline__ void conv_mainloop(__bf16* As, __bf16* Bs, int K, float (&ra)[CKU][4], float (&rb)[CKU][4], FA fetch_a,
-                                              FB fetch_b, f32x16 (&acc)[2][2]) {
+                                              FB fetch_b, f32x16 (&acc)[2][2], int kbeg = 0) {
     constexpr int TPR = CBK / 4, RPP = CNT / TPR;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
-    fetch_a(0); fetch_b(0);
-    for (int k0 = 0; k0 < K; k0 += CBK) {
+    if (kbeg < K) { fetch_a(kbeg); fetch_b(kbeg); }
+    for (int k0 = kbeg; k0 < K; k0 += CBK) {
         __syncthreads();
+        if (A_KCONT) {
 #pragma unroll
-        for (int u = 0; u < CKU; ++u) {
-            const bf16x4 h = {(__bf16)ra[u][0], (__bf16)ra[u][1], (__bf16)ra[u][2], (__bf16)ra[u][3]};
-            *reinterpret_cast<bf16x4*>(&As[(t / TPR + RPP * u) * CSTR + (t % TPR) * 4]) = h;
+            for (int u = 0; u < CKU; ++u) {
+                const bf16x4 h = {(__bf16)ra[u][0], (__bf16)ra[u][1], (__bf16)ra[u][2], (__bf16)ra[u][3]};
+                *reinterpret_cast<bf16x4*>(&As[(t / TPR + RPP * u) * CSTR + (t % TPR) * 4]) = h;
+            }
+        } else {
+            __bf16* rowp = As + (t & 127) * CSTR + (CBK / 2) * (t >> 7);
+#pragma unroll
+            for (int h = 0; h < CKU / 2; ++h) {
+                const bf16x8 w8 = {(__bf16)ra[2 * h][0], (__bf16)ra[2 * h][1], (__bf16)ra[2 * h][2], (__bf16)ra[2 * h][3],
+                                   (__bf16)ra[2 * h + 1][0], (__bf16)ra[2 * h + 1][1], (__bf16)ra[2 * h + 1][2], (__bf16)ra[2 * h + 1][3]};
+                *reinterpret_cast<bf16x8*>(rowp + 8 * h) = w8;
+            }
         }
         if (B_KCONT) {
 #pragma unroll
@@ -295,9 +306,125 @@ __global__ __launch_bounds__(CNT) void conv_t_fwd_kernel(const ConvTArgs g) {
     }
 }
 
+// ---- kernel gradient -------------------------------------------------------------------------------------------------------------
+//   dK[kh, kw, c, o] = sum_{n, i, j} x[n, 2 i + kh - 1, 2 j + kw - 1, c] dy[n, i, j, o];   db[o] = sum_{n, i, j} dy[n, i, j, o]
+// GEMM rows m = (kh, kw, c) plus one row of ones (db), columns o, inner index = the output pixels, split over the batch into S
+// slabs that a fixed-order sum adds afterwards (no float atomics: bitwise repeatable, like the Dense dW|db).  Both operands have
+// the inner index strided in memory: thread = one row (resp. column) and 16 consecutive pixels, staged transposed with 16-byte
+// LDS writes.  With (x := dL/d out, dy := the layer's input) the same kernel is the TRANSPOSED layer's kernel gradient
+// [kh, kw, C_out, C_in].
+struct ConvWArgs {
+    const float* x; const float* dy; float* slab;
+    int B, H, W, Cin, Cout, Ho, Wo;
+    int M, N, K;                        // M = 16 Cin + 1, N = Cout, K = B Ho Wo
+    int k_per_split; long long slab_stride;
+};
+
+__global__ __launch_bounds__(CNT) void conv_wgrad_kernel(const ConvWArgs g) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[CBM * CSTR];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[CBN * CSTR];
+    const int m0 = blockIdx.y * CBM, n0 = blockIdx.x * CBN;
+    const int kbeg = blockIdx.z * g.k_per_split, kend = min(g.K, kbeg + g.k_per_split);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // A: this thread's row m = (kh, kw, c) -- or the row of ones
+    const int m = m0 + (t & 127), mreal = g.M - 1;
+    const bool a_row = m < mreal, a_one = m == mreal;
+    const int mc = a_row ? m : 0, tap = mc / g.Cin, ch = mc % g.Cin, kh = tap >> 2, kw = tap & 3;
+    const int col = n0 + (t & 127), colc = min(col, g.N - 1);
+    float ra[CKU][4], rb[CKU][4];
+    auto fetch_a = [&](int k0) {
+        const int pb = k0 + (CBK / 2) * (t >> 7);
+#pragma unroll
+        for (int u = 0; u < CKU; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                  // unconditional at a clamped address, selected afterwards
+                const int p = pb + 4 * u + c, pc = min(p, g.K - 1);
+                const int n = pc / (g.Ho * g.Wo), ij = pc % (g.Ho * g.Wo), yy = 2 * (ij / g.Wo) + kh - 1, xx = 2 * (ij % g.Wo) + kw - 1;
+                const bool in = a_row && p < kend && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+                const int yc = min(max(yy, 0), g.H - 1), xc = min(max(xx, 0), g.W - 1);
+                const float f = g.x[(((long long)n * g.H + yc) * g.W + xc) * g.Cin + ch];
+                ra[u][c] = in ? f : ((a_one && p < kend) ? 1.f : 0.f);
+            }
+    };
+    auto fetch_b = [&](int k0) {
+        const int pb = k0 + (CBK / 2) * (t >> 7);
+#pragma unroll
+        for (int u = 0; u < CKU; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int p = pb + 4 * u + c;
+                const float f = g.dy[(long long)min(p, g.K - 1) * g.N + colc];
+                rb[u][c] = (p < kend && col < g.N) ? f : 0.f;
+            }
+    };
+    conv_mainloop<false, false>(As, Bs, kend, ra, rb, fetch_a, fetch_b, acc, kbeg);
+    float* C = g.slab + (long long)blockIdx.z * g.slab_stride;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int cc = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (cc >= g.N) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < g.M) C[(long long)row * g.N + cc] = acc[i][j][r];
+            }
+    }
+}
+
+static int conv_wgrad_splits(long long pixels, int M, int N) {
+    const long long tiles = (long long)((M + CBM - 1) / CBM) * ((N + CBN - 1) / CBN);
+    long long S = std::max(1ll, 1024 / tiles);
+    S = std::min(S, std::max(1ll, pixels / 256));          // at least 256 pixels (8 k-tiles) per split
+    return (int)std::min(S, 4096ll);
+}
+
 }  // namespace vaek
 
 using namespace vaek;
+
+extern "C" int vaek_conv2d_weight_grad_workspace(int32_t batch, int32_t height, int32_t width, int32_t c_in, int32_t c_out, size_t* bytes) {
+    if (!bytes || batch < 1 || height < 2 || width < 2 || c_in < 1 || c_out < 1) { set_error("vaek_conv2d_weight_grad_workspace: invalid argument"); return VAEK_ERR_INVALID; }
+    const long long pixels = (long long)batch * (height / 2) * (width / 2);
+    const int M = 16 * c_in + 1;
+    *bytes = (size_t)conv_wgrad_splits(pixels, M, c_out) * M * c_out * sizeof(float);
+    return VAEK_OK;
+}
+
+extern "C" int vaek_conv2d_weight_grad(const float* x, const float* dy, float* dw, float* dbias, void* workspace, int32_t batch,
+                                       int32_t height, int32_t width, int32_t c_in, int32_t c_out, void* stream) {
+    if (!x || !dy || !dw || !workspace || batch < 1 || height < 2 || width < 2 || (height & 1) || (width & 1) || c_in < 1 || c_out < 1) {
+        set_error("vaek_conv2d_weight_grad: invalid argument");
+        return VAEK_ERR_INVALID;
+    }
+    ConvWArgs g{};
+    g.x = x; g.dy = dy; g.slab = static_cast<float*>(workspace);
+    g.B = batch; g.H = height; g.W = width; g.Cin = c_in; g.Cout = c_out; g.Ho = height / 2; g.Wo = width / 2;
+    const long long pixels = (long long)batch * g.Ho * g.Wo;
+    if (pixels > 0x7fffffffll) { set_error("vaek_conv2d_weight_grad: too many pixels"); return VAEK_ERR_INVALID; }
+    g.M = 16 * c_in + 1; g.N = c_out; g.K = (int)pixels;
+    const int S = conv_wgrad_splits(pixels, g.M, g.N);
+    g.k_per_split = (int)(((pixels + S - 1) / S + CBK - 1) / CBK * CBK);
+    g.slab_stride = (long long)g.M * g.N;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        ProfScope ps("conv_wgrad_bf16", st);
+        launch_k(ps, conv_wgrad_kernel, dim3((g.N + CBN - 1) / CBN, (g.M + CBM - 1) / CBM, S), dim3(CNT), 0, st, g);
+        VAEK_HIP_CHECK(hipGetLastError());
+    }
+    int rc = launch_sum_slabs(g.slab, g.slab_stride, S, dw, (int64_t)16 * c_in * c_out, st);
+    if (rc == VAEK_OK && dbias) rc = launch_sum_slabs(g.slab + (long long)16 * c_in * c_out, g.slab_stride, S, dbias, c_out, st);
+    return rc;
+}
 
 extern "C" int vaek_conv2d_transpose_forward(const float* y, const float* w, const float* bias, const float* mask, float* out,
                                              int32_t batch, int32_t height, int32_t width, int32_t c_in, int32_t c_out, int32_t relu,
