@@ -241,8 +241,8 @@ int vaek_train_steps_status(vaek_ctx* ctx, void* workspace, int32_t* gave_up);
  *   y[n, i, j, o] = act(bias[o] + sum_{kh, kw, c} x[n, 2 i + kh - 1, 2 j + kw - 1, c] * w[kh, kw, c, o]),  y: [batch, height/2, width/2, c_out].
  * No context needed.  With the two entry points below every product of both layer kinds' forward and backward passes exists; the
  * convolutional VAE's train step is not assembled yet. */
-int vaek_conv2d_forward(const float* x, const float* w, const float* bias, float* y, int32_t batch, int32_t height, int32_t width,
-                        int32_t c_in, int32_t c_out, int32_t relu, void* stream);
+int vaek_conv2d_forward(const float* x, const float* w, const float* bias, const float* mask, float* y, int32_t batch, int32_t height,
+                        int32_t width, int32_t c_in, int32_t c_out, int32_t relu, void* stream);   /* mask: as below; NULL = none */
 /* The transposed convolution of the same specification = the adjoint of vaek_conv2d_forward with the SAME kernel array
  * (oracle: conv_t_fwd): y [batch, height, width, c_in], w [4][4][c_out][c_in] (the HWIO kernel of the convolution it is the adjoint
  * of), out [batch, 2 height, 2 width, c_out] = act(bias + ...).  It is also the convolution's input gradient (y := dL/d output, bias
@@ -256,6 +256,16 @@ int vaek_conv2d_transpose_forward(const float* y, const float* w, const float* b
 int vaek_conv2d_weight_grad_workspace(int32_t batch, int32_t height, int32_t width, int32_t c_in, int32_t c_out, size_t* bytes);
 int vaek_conv2d_weight_grad(const float* x, const float* dy, float* dw, float* dbias, void* workspace, int32_t batch, int32_t height,
                             int32_t width, int32_t c_in, int32_t c_out, void* stream);
+/* dbias[c] = sum over the pixels of dy[pixels][c] (the bias gradient of a transposed layer); workspace: 512 * c floats. */
+int vaek_conv2d_bias_grad(const float* dy, float* dbias, void* workspace, int64_t pixels, int32_t c, void* stream);
+/* Dense + reparameterisation (networks.py:72-74) as one block: mu = x @ w + b, samples = mu + exp(logvar_e / 2) * z1. */
+int vaek_dense_fwd_reparam(vaek_ctx* ctx, const float* x, const float* w, const float* b, float* mu, float* samples, const float* z1,
+                           const float* logvar_e, int32_t rows, int32_t n_in, int32_t n_out, void* stream);
+/* Backward of the reparameterisation + the KL term's mu and logvar_e parts (what jax.value_and_grad does with networks.py:73-74, 94):
+ * in place d_samples -> d_mu = d_samples + mu / batch_total; d_logvar_e[l] = 0.5 exp(lv_l / 2) sum_rows d_samples z1
+ * - 0.5 (1 - exp(lv_l)) rows / batch_total.  latent_dim <= 256. */
+int vaek_reparam_bwd(vaek_ctx* ctx, float* d_samples, const float* mu, const float* z1, const float* logvar_e, float* d_logvar_e,
+                     int32_t rows, int32_t latent_dim, int64_t batch_total, void* workspace, void* stream);
 /* n standard normals and/or the raw Philox words they came from (block b = counter (b_lo, b_hi, step, tag)). */
 int vaek_rng_fill(vaek_ctx* ctx, float* normals, uint32_t* bits, int64_t n, uint64_t seed, uint32_t step, uint32_t tag,
                   void* stream);

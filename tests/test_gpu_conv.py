@@ -122,3 +122,122 @@ def test_transposed_layer_backward_from_the_same_three_kernels():
     got_dK = conv2d_weight_grad(_dev(dout), _dev(y), want_bias=False)[0].cpu().numpy().astype(np.float64)
     assert np.max(np.abs(got_dy - want_dy)) <= 1e-2 * np.max(np.abs(want_dy))
     assert got_dK.shape == want_dK.shape and np.max(np.abs(got_dK - want_dK)) <= 1e-2 * np.max(np.abs(want_dK))
+
+
+def _conv_problem(cfg, B, seed=0):
+    rng = np.random.default_rng(seed)
+    r32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    p = {k: r32(v) for k, v in CO.init_params(cfg, seed=seed + 1).items()}
+    for k in p:
+        if not k.endswith("kernel"):
+            p[k] = r32(p[k] + 0.1 * rng.standard_normal(p[k].shape))
+    return p, r32(rng.random((B, cfg.S, cfg.S, 1))), r32(rng.standard_normal((B, cfg.L))), r32(rng.standard_normal((B, cfg.S, cfg.S, 1)))
+
+
+def _bf16_emulation_grads(cfg, p, x, z1, z2):
+    """The same network in torch float64 on the CPU with every convolution product's OPERANDS rounded to bf16 where the HIP kernels
+    round them (forward, input gradient and kernel gradient of both layer kinds; relu masks, biases, Dense layers and the ELBO
+    unrounded): what the kernels compute up to the order of the float32 accumulation."""
+    import math
+    import torch.nn.functional as F
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float64)
+
+    class Conv(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, h, w, b):                      # h NCHW, w OIHW
+            ctx.save_for_backward(h, w)
+            return F.conv2d(rb(h), rb(w), b, stride=2, padding=1)
+
+        @staticmethod
+        def backward(ctx, dy):
+            h, w = ctx.saved_tensors
+            dh = F.conv_transpose2d(rb(dy), rb(w), None, stride=2, padding=1)
+            dw = torch.nn.grad.conv2d_weight(rb(h), w.shape, rb(dy), stride=2, padding=1)
+            return dh, dw, dy.sum(dim=(0, 2, 3))
+
+    class ConvT(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, h, w, b):                      # w [C_in, C_out, 4, 4] (torch's transposed layout)
+            ctx.save_for_backward(h, w)
+            return F.conv_transpose2d(rb(h), rb(w), b, stride=2, padding=1)
+
+        @staticmethod
+        def backward(ctx, dout):
+            h, w = ctx.saved_tensors
+            dh = F.conv2d(rb(dout), rb(w), None, stride=2, padding=1)
+            dw = torch.nn.grad.conv2d_weight(rb(dout), w.shape, rb(h), stride=2, padding=1)
+            return dh, dw, dout.sum(dim=(0, 2, 3))
+
+    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    xt, z1t, z2t = (torch.tensor(a, dtype=torch.float64) for a in (x, z1, z2))
+    B = x.shape[0]
+    h = xt.permute(0, 3, 1, 2)
+    for i in range(4):
+        h = torch.relu(Conv.apply(h, tp[f"Encoder/Conv{i}/kernel"].permute(3, 2, 0, 1), tp[f"Encoder/Conv{i}/bias"]))
+    flat = h.permute(0, 2, 3, 1).reshape(B, -1)
+    mu = flat @ tp["Encoder/FC/kernel"] + tp["Encoder/FC/bias"]
+    lv = tp["epsilon_p"]
+    samples = mu + torch.exp(lv / 2) * z1t
+    d = torch.relu(samples @ tp["Decoder/FC/kernel"] + tp["Decoder/FC/bias"])
+    h = d.reshape(B, cfg.S // 16, cfg.S // 16, cfg.widths[3]).permute(0, 3, 1, 2)
+    for i in range(4):
+        h = ConvT.apply(h, tp[f"Decoder/ConvT{i}/kernel"].permute(3, 2, 0, 1), tp[f"Decoder/ConvT{i}/bias"])
+        if i < 3:
+            h = torch.relu(h)
+    eps = tp["epsilon"][0] * cfg.epsilon if cfg.tdv else torch.tensor(cfg.epsilon, dtype=torch.float64)
+    x_hat = h.permute(0, 2, 3, 1) + z2t * torch.exp(eps / 2)
+    dkl = -0.5 * torch.sum(1 + lv - torch.exp(lv) - mu ** 2, dim=-1)
+    mse = (0.5 * ((x_hat - xt) ** 2).reshape(B, -1) / torch.exp(eps) + 0.5 * (math.log(2 * math.pi) + eps)).sum(dim=-1)
+    loss = (dkl + mse).mean()
+    loss.backward()
+    return loss.item(), {k: t.grad.numpy() for k, t in tp.items()}
+
+
+@pytest.mark.parametrize("size,widths,L,B,tdv", [(16, (4, 8, 8, 16), 5, 6, True), (32, (8, 16, 16, 32), 7, 4, False), (64, (4, 8, 8, 16), 8, 3, True)])
+def test_conv_vae_loss_and_every_gradient_leaf(size, widths, L, B, tdv):
+    """The whole convolutional VAE -- forward, ELBO, backward assembled from the library's blocks -- against (i) the
+    same arithmetic emulated in float64 with the convolution operands rounded to bf16 where the kernels round them (tight: the
+    kernels compute THAT), and (ii) the float64 oracle (the bf16 envelope: through 8 convolution layers each way the first
+    layers' gradients carry rounding noise and flipped relus: rms up to 0.2 of a leaf's rms at these tiny widths and batches)."""
+    from vae_training_amd.conv_vae import ConvVAE
+    cfg = CO.ConvConfig(size, widths, L, -1.5, tdv)
+    p, x, z1, z2 = _conv_problem(cfg, B)
+    loss, g = CO.loss_and_grad(cfg, p, x, z1, z2)
+    eloss, eg = _bf16_emulation_grads(cfg, p, x, z1, z2)
+    net = ConvVAE(B, size, widths, L, -1.5, tdv)
+    assert [n for n, _ in net.leaf_shapes()] == [n for n, _ in cfg.leaves()] and net.P == cfg.n_params()
+    params, grads = net.new_flat(), net.new_flat()
+    for name in net.leaves:
+        net.view(params, name).copy_(_dev(p[name]))
+    out4 = net.loss_and_grad(params, grads, _dev(x), _dev(z1), _dev(z2)).cpu().numpy().astype(np.float64)
+    assert abs(out4[0] - eloss) <= 2e-5 * abs(eloss), (out4[0], eloss)
+    assert abs(out4[0] - loss) <= 2e-3 * abs(loss), (out4[0], loss)
+    for name in net.leaves:
+        got = net.view(grads, name).cpu().numpy().astype(np.float64)
+        assert got.shape == g[name].shape, name
+        emu, want = eg[name], g[name]
+        assert np.max(np.abs(got - emu)) <= 5e-3 * (np.max(np.abs(emu)) + 1e-30), (name, np.max(np.abs(got - emu)), np.max(np.abs(emu)))
+        assert np.sqrt(np.mean((got - want) ** 2)) <= 0.3 * (np.sqrt(np.mean(want ** 2)) + 1e-30), name
+
+
+def test_conv_vae_train_steps_reduce_the_loss_like_the_oracle():
+    from oracle import elbo_oracle as O
+    from vae_training_amd.conv_vae import ConvVAE
+    cfg = CO.ConvConfig(16, (4, 8, 8, 16), 5, -1.5, True)
+    B, lr = 8, 2e-3
+    p, x, z1, z2 = _conv_problem(cfg, B, seed=3)
+    net = ConvVAE(B, 16, (4, 8, 8, 16), 5, -1.5, True)
+    params, grads, m, v = net.new_flat(), net.new_flat(), net.new_flat(), net.new_flat()
+    for name in net.leaves:
+        net.view(params, name).copy_(_dev(p[name]))
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    st = O.adam_init(p)
+    got, want = [], []
+    for k in range(6):
+        loss, g = CO.loss_and_grad(cfg, p, x, z1, z2)
+        p, st = O.adam_update(p, g, st, lr)
+        want.append(loss)
+        got.append(float(net.train_step(params, grads, m, v, step, _dev(x), _dev(z1), _dev(z2), lr)[0]))
+    got, want = np.array(got), np.array(want)
+    assert int(step.item()) == 6 and got[-1] < got[0]
+    assert np.max(np.abs(got - want) / np.abs(want)) <= 1e-2, (got, want)

@@ -1,0 +1,112 @@
+"""Convolutional VAE (BASELINE config 5) -- host side.  NO reference counterpart: the reference has no convolutional model; the
+architecture is this repository's own specification and oracle/conv_vae_oracle.py is the checker.  What IS the
+reference's is everything around the two networks: epsilon_p as the latent log-variance (networks.py:68-72), the
+reparameterisation (:73-74), decoder noise and the tunable decoder variance (:70-71, 81-83), the ELBO (:94-98), Adam (:100).
+
+A train step is assembled here from the library's blocks (include/vaek.h), every product on the GPU through the C ABI:
+  encoder   4 x vaek_conv2d_forward (relu)  ->  vaek_dense_fwd_reparam (mu, samples)
+  decoder   vaek_dense_fwd (relu)  ->  4 x vaek_conv2d_transpose_forward (relu between, linear output)
+  loss      vaek_elbo_fwd_bwd (decoder noise, KL, Gaussian likelihood, dL/dx_hat, dL/d eps)
+  backward  vaek_conv2d_weight_grad / vaek_conv2d_bias_grad / vaek_conv2d_forward (the transposed layers' input gradient) /
+            vaek_dense_bwd_dw / vaek_dense_bwd_dx / vaek_reparam_bwd / vaek_conv2d_transpose_forward (the convolutions' input
+            gradient, the relu of the layer below applied as a mask)
+  update    vaek_adam_step over the flat parameter vector
+Parameters, gradients and Adam moments are ONE flat float32 buffer each, in the leaf order of ConvVAE.leaves() (the oracle's);
+PyTorch holds the device memory and slices views -- it computes nothing.  This is a first, launch-per-layer assembly (about 40
+launches per step, and one host read of the epsilon parameter per step): correct first, not fast yet."""
+import math
+
+import torch
+
+from .conv import conv2d_bias_grad, conv2d_forward, conv2d_transpose_forward, conv2d_weight_grad
+from .engine import Engine
+
+KS = 4
+
+
+class ConvVAE:
+    def __init__(self, batch, size=64, widths=(32, 64, 128, 256), latent_dim=32, epsilon=-3.0, tunable_decoder_var=True, device=0):
+        assert size % 16 == 0 and len(widths) == 4
+        self.B, self.S, self.widths, self.L, self.eps_cli, self.tdv = batch, size, tuple(widths), latent_dim, float(epsilon), tunable_decoder_var
+        self.bott = (size // 16) ** 2 * widths[3]
+        # the block entry points want a context: a linear VAE of the same batch / widest Dense side sizes their workspaces
+        self.eng = Engine(batch, max(size * size, self.bott), latent_dim, (), (), epsilon, tunable_decoder_var, False, device=device,
+                          force_generic=True)
+        self.device = self.eng.device
+        off, self.leaves = 0, {}
+        for name, shape in self.leaf_shapes():
+            n = math.prod(shape)
+            self.leaves[name] = (off, shape)
+            off += n
+        self.P = off
+
+    def leaf_shapes(self):
+        out, cin = [], 1
+        for i, c in enumerate(self.widths):
+            out += [(f"Encoder/Conv{i}/kernel", (KS, KS, cin, c)), (f"Encoder/Conv{i}/bias", (c,))]
+            cin = c
+        out += [("Encoder/FC/kernel", (self.bott, self.L)), ("Encoder/FC/bias", (self.L,)),
+                ("Decoder/FC/kernel", (self.L, self.bott)), ("Decoder/FC/bias", (self.bott,))]
+        chans = [self.widths[3], self.widths[2], self.widths[1], self.widths[0], 1]
+        for i in range(4):
+            out += [(f"Decoder/ConvT{i}/kernel", (KS, KS, chans[i + 1], chans[i])), (f"Decoder/ConvT{i}/bias", (chans[i + 1],))]
+        out.append(("epsilon_p", (self.L,)))
+        if self.tdv:
+            out.append(("epsilon", (1,)))
+        return out
+
+    def view(self, flat, name):
+        off, shape = self.leaves[name]
+        return flat[off:off + math.prod(shape)].view(*shape)
+
+    def new_flat(self):
+        return torch.zeros(self.P, dtype=torch.float32, device=self.device)
+
+    def loss_and_grad(self, params, grads, x, z1, z2):
+        """x, z2 [B, S, S, 1], z1 [B, L] (contiguous float32 on the device); writes the flat gradient, returns the device
+        tensor {loss, mean Dkl, mean mse, dL/d eps}."""
+        B, S, L, e = x.shape[0], self.S, self.L, self.eng
+        P = lambda n: self.view(params, n)
+        G = lambda n: self.view(grads, n)
+        # ---- forward
+        acts = [x]
+        for i in range(4):
+            acts.append(conv2d_forward(acts[-1], P(f"Encoder/Conv{i}/kernel"), P(f"Encoder/Conv{i}/bias"), relu=True))
+        flat = acts[-1].view(B, self.bott)
+        lv = P("epsilon_p")
+        mu, samples = e.dense_fwd_reparam(flat, P("Encoder/FC/kernel"), P("Encoder/FC/bias"), z1, lv)
+        dec = [e.dense_fwd(samples, P("Decoder/FC/kernel"), P("Decoder/FC/bias"), relu=True).view(B, S // 16, S // 16, self.widths[3])]
+        for i in range(4):
+            dec.append(conv2d_transpose_forward(dec[-1], P(f"Decoder/ConvT{i}/kernel"), P(f"Decoder/ConvT{i}/bias"), relu=i < 3))
+        eps = float(P("epsilon")[0]) * self.eps_cli if self.tdv else self.eps_cli        # one host read per step (see the module text)
+        out4, d, _ = e.elbo_fwd_bwd(x.view(B, S * S), dec[4].view(B, S * S), None, z2.view(B, S * S), mu, lv, eps)
+        # ---- backward: decoder
+        d = d.view(B, S, S, 1)
+        for i in reversed(range(4)):
+            inp = dec[i]
+            conv2d_weight_grad(d, inp, want_bias=False, dw=G(f"Decoder/ConvT{i}/kernel"))
+            conv2d_bias_grad(d, G(f"Decoder/ConvT{i}/bias"))
+            d = conv2d_forward(d, P(f"Decoder/ConvT{i}/kernel"), None, relu=False, mask=inp)      # adjoint of the adjoint + relu below
+        d = d.view(B, self.bott)
+        off, _ = self.leaves["Decoder/FC/kernel"]
+        grads[off:off + (L + 1) * self.bott].copy_(e.dense_bwd_dw(samples, d).view(-1))         # [kernel | bias] is contiguous
+        d_s = e.dense_bwd_dx(d, P("Decoder/FC/kernel"))
+        e.reparam_bwd(d_s, mu, z1, lv, out=G("epsilon_p"))                                        # d_s becomes d_mu in place
+        off, _ = self.leaves["Encoder/FC/kernel"]
+        grads[off:off + (self.bott + 1) * L].copy_(e.dense_bwd_dw(flat, d_s).view(-1))
+        d = e.dense_bwd_dx(d_s, P("Encoder/FC/kernel"), flat, relu=True).view(B, S // 16, S // 16, self.widths[3])
+        # ---- backward: encoder
+        for i in reversed(range(4)):
+            inp = acts[i]
+            conv2d_weight_grad(inp, d, dw=G(f"Encoder/Conv{i}/kernel"), db=G(f"Encoder/Conv{i}/bias"))
+            if i > 0:
+                d = conv2d_transpose_forward(d, P(f"Encoder/Conv{i}/kernel"), None, relu=False, mask=inp)
+        if self.tdv:
+            G("epsilon").copy_(out4[3:4] * self.eps_cli)                                          # eps = param * eps_cli
+        return out4
+
+    def train_step(self, params, grads, m, v, step_dev, x, z1, z2, lr):
+        out4 = self.loss_and_grad(params, grads, x, z1, z2)
+        step_dev += 1
+        self.eng.adam_step(params, grads, m, v, lr, step_dev=step_dev)
+        return out4

@@ -518,6 +518,46 @@ int vaek_dense_fwd(vaek_ctx* ctx, const float* x, const float* w, const float* b
     return launch_dense_fwd(x, w, b, y, rows, n_in, n_out, act == VAEK_ACT_RELU, (hipStream_t)stream);
 }
 
+int vaek_dense_fwd_reparam(vaek_ctx* ctx, const float* x, const float* w, const float* b, float* mu, float* samples, const float* z1,
+                           const float* logvar_e, int32_t rows, int32_t n_in, int32_t n_out, void* stream) {
+    if (!ctx || !x || !w || !mu || !samples || !z1 || !logvar_e || rows <= 0 || n_in <= 0 || n_out <= 0) {
+        set_error("vaek_dense_fwd_reparam: invalid argument");
+        return VAEK_ERR_INVALID;
+    }
+    return launch_dense_fwd_reparam(x, w, b, mu, samples, z1, logvar_e, rows, n_in, n_out, (hipStream_t)stream);
+}
+
+// d logvar_e from the per-split sums of d_samples * z1 (fixed order) and the closed-form KL part
+__global__ void reparam_finish_kernel(const float* partial, int S, int L, const float* lv, float rows_over_bt, float* out) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    float acc = 0.f;
+    for (int s2 = 0; s2 < S; ++s2) acc += partial[(long long)s2 * L + l];
+    const float v = lv[l];
+    out[l] = 0.5f * expf(0.5f * v) * acc - 0.5f * (1.f - expf(v)) * rows_over_bt;
+}
+
+int vaek_reparam_bwd(vaek_ctx* ctx, float* d_samples, const float* mu, const float* z1, const float* logvar_e, float* d_logvar_e,
+                     int32_t rows, int32_t latent_dim, int64_t batch_total, void* workspace, void* stream) {
+    if (!ctx || !d_samples || !mu || !z1 || !logvar_e || !d_logvar_e || rows <= 0 || latent_dim <= 0 || latent_dim > 256) {
+        set_error("vaek_reparam_bwd: invalid argument");
+        return VAEK_ERR_INVALID;
+    }
+    int rc = check_ws(ctx, workspace);
+    if (rc) return rc;
+    const double bt = batch_total > 0 ? (double)batch_total : (double)rows;
+    const int S = std::max(1, std::min(ctx->Se, (int)(((size_t)ctx->Se * ctx->L) / latent_dim)));     // what the context's partial area holds
+    const int rps = (rows + S - 1) / S;
+    const int Su = (rows + rps - 1) / rps;
+    float* part = at<float>(workspace, ctx->ws_rpart);
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = launch_reparam_bwd(d_samples, mu, z1, part, rows, latent_dim, Su, rps, (float)(1.0 / bt), st))) return rc;
+    hipLaunchKernelGGL(reparam_finish_kernel, dim3((latent_dim + 63) / 64), dim3(64), 0, st, (const float*)part, Su, (int)latent_dim, logvar_e,
+                       (float)((double)rows / bt), d_logvar_e);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
 int vaek_dense_bwd_dx(vaek_ctx* ctx, const float* dy, const float* w, const float* x_post, float* dx, int32_t rows,
                       int32_t n_in, int32_t n_out, int32_t act, int32_t accumulate, void* stream) {
     if (!ctx || !dy || !w || !dx || rows <= 0 || n_in <= 0 || n_out <= 0 || (act == VAEK_ACT_RELU && !x_post) ||

@@ -25,7 +25,7 @@ using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 constexpr int CBM = 128, CBN = 128, CNT = 256, CBK = 32, CSTR = CBK + 8, CKU = CBK / 8;
 
 struct ConvArgs {
-    const float* x; const float* w; const float* bias; float* y;
+    const float* x; const float* w; const float* bias; const float* mask; float* y;
     int B, H, W, Cin, Cout, Ho, Wo;
     int M, N, K;                        // M = B Ho Wo, N = Cout, K = 16 Cin
     int relu;
@@ -173,6 +173,7 @@ __global__ __launch_bounds__(CNT) void conv_fwd_kernel(const ConvArgs g) {
                 if (row >= g.M) continue;
                 float v = acc[i][j][r] + bias;
                 if (g.relu) v = fmaxf(v, 0.f);
+                if (g.mask) v = g.mask[(long long)row * g.N + col] > 0.f ? v : 0.f;
                 g.y[(long long)row * g.N + col] = v;
             }
     }
@@ -381,6 +382,27 @@ __global__ __launch_bounds__(CNT) void conv_wgrad_kernel(const ConvWArgs g) {
     }
 }
 
+// column sums of dy [pixels][C] (the bias gradient of a transposed layer: its dL/d out summed over the pixels): block s sums its
+// rows per column, a fixed-order sum over the blocks follows (launch_sum_slabs)
+__global__ __launch_bounds__(256) void conv_colsum_kernel(const float* dy, float* partial, long long pixels, int C, long long rows_per_split) {
+    extern __shared__ float sh[];   // 256 floats
+    const long long r0 = blockIdx.x * rows_per_split, r1 = min(pixels, r0 + rows_per_split);
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int W = min(256, C - c0), G = 256 / W, col = threadIdx.x % W, grp = threadIdx.x / W;
+        float acc = 0.f;
+        if (grp < G)
+            for (long long r = r0 + grp; r < r1; r += G) acc += dy[r * C + c0 + col];
+        sh[threadIdx.x] = grp < G ? acc : 0.f;
+        __syncthreads();
+        if ((int)threadIdx.x < W) {
+            float tsum = 0.f;
+            for (int g2 = 0; g2 < G; ++g2) tsum += sh[g2 * W + threadIdx.x];
+            partial[(long long)blockIdx.x * C + c0 + threadIdx.x] = tsum;
+        }
+        __syncthreads();
+    }
+}
+
 static int conv_wgrad_splits(long long pixels, int M, int N) {
     const long long tiles = (long long)((M + CBM - 1) / CBM) * ((N + CBN - 1) / CBN);
     long long S = std::max(1ll, 1024 / tiles);
@@ -426,6 +448,19 @@ extern "C" int vaek_conv2d_weight_grad(const float* x, const float* dy, float* d
     return rc;
 }
 
+extern "C" int vaek_conv2d_bias_grad(const float* dy, float* dbias, void* workspace, int64_t pixels, int32_t c, void* stream) {
+    if (!dy || !dbias || !workspace || pixels < 1 || c < 1) { set_error("vaek_conv2d_bias_grad: invalid argument"); return VAEK_ERR_INVALID; }
+    const int S = (int)std::min<long long>(512, (pixels + 255) / 256);
+    const long long rps = (pixels + S - 1) / S;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        ProfScope ps("conv_bias_grad", st);
+        launch_k(ps, conv_colsum_kernel, dim3(S), dim3(256), 256 * sizeof(float), st, dy, static_cast<float*>(workspace), (long long)pixels, (int)c, rps);
+        VAEK_HIP_CHECK(hipGetLastError());
+    }
+    return launch_sum_slabs(static_cast<const float*>(workspace), c, S, dbias, c, st);
+}
+
 extern "C" int vaek_conv2d_transpose_forward(const float* y, const float* w, const float* bias, const float* mask, float* out,
                                              int32_t batch, int32_t height, int32_t width, int32_t c_in, int32_t c_out, int32_t relu,
                                              void* stream) {
@@ -445,14 +480,14 @@ extern "C" int vaek_conv2d_transpose_forward(const float* y, const float* w, con
     return VAEK_OK;
 }
 
-extern "C" int vaek_conv2d_forward(const float* x, const float* w, const float* bias, float* y, int32_t batch, int32_t height,
-                                   int32_t width, int32_t c_in, int32_t c_out, int32_t relu, void* stream) {
+extern "C" int vaek_conv2d_forward(const float* x, const float* w, const float* bias, const float* mask, float* y, int32_t batch,
+                                   int32_t height, int32_t width, int32_t c_in, int32_t c_out, int32_t relu, void* stream) {
     if (!x || !w || !y || batch < 1 || height < 2 || width < 2 || (height & 1) || (width & 1) || c_in < 1 || c_out < 1) {
         set_error("vaek_conv2d_forward: invalid argument");
         return VAEK_ERR_INVALID;
     }
     ConvArgs g{};
-    g.x = x; g.w = w; g.bias = bias; g.y = y;
+    g.x = x; g.w = w; g.bias = bias; g.mask = mask; g.y = y;
     g.B = batch; g.H = height; g.W = width; g.Cin = c_in; g.Cout = c_out; g.Ho = height / 2; g.Wo = width / 2;
     const long long M = (long long)batch * g.Ho * g.Wo;
     if (M > 0x7fffffffll || (M + CBM - 1) / CBM > 65535) { set_error("vaek_conv2d_forward: too many output pixels"); return VAEK_ERR_INVALID; }

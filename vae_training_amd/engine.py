@@ -288,6 +288,24 @@ class Engine:
                                            int(relu), _stream()))
         return y
 
+    def dense_fwd_reparam(self, x, w, b, z1, logvar_e):
+        """mu = x @ w + b, samples = mu + exp(logvar_e / 2) * z1 (networks.py:72-74) in one block."""
+        rows, n_in = x.shape
+        n_out = w.shape[1]
+        mu = torch.empty(rows, n_out, dtype=torch.float32, device=self.device)
+        samples = torch.empty_like(mu)
+        _lib.check(self.lib.vaek_dense_fwd_reparam(self.h, _ptr(x), _ptr(w), _ptr(b), _ptr(mu), _ptr(samples), _ptr(z1), _ptr(logvar_e),
+                                                   rows, n_in, n_out, _stream()))
+        return mu, samples
+
+    def reparam_bwd(self, d_samples, mu, z1, logvar_e, batch_total=0, out=None):
+        """In place d_samples -> d_mu; returns d logvar_e (reparameterisation + KL parts)."""
+        rows, L = mu.shape
+        g = torch.empty(L, dtype=torch.float32, device=self.device) if out is None else out
+        _lib.check(self.lib.vaek_reparam_bwd(self.h, _ptr(d_samples), _ptr(mu), _ptr(z1), _ptr(logvar_e), _ptr(g), rows, L,
+                                             int(batch_total), _ptr(self.workspace), _stream()))
+        return g
+
     def dense_bwd_dx(self, dy, w, x_post=None, relu=False, out=None, accumulate=False):
         rows, n_out = dy.shape
         n_in = w.shape[0]
