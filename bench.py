@@ -214,7 +214,68 @@ def cpu_baseline_c1(seconds_each=1.5):
     return legs
 
 
+def bench_conv(args):
+    """Workload C5 (BASELINE config 5; no reference counterpart): the convolutional VAE's train step assembled from the
+    library's blocks (vae_training_amd/conv_vae.py), one GPU, eager launches.  Its own line: same metric and unit."""
+    import torch
+
+    from vae_training_amd.conv_vae import ConvVAE
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        sys.exit("bench.py --workload C5: single GPU only so far")
+    S, widths, L = 64, (32, 64, 128, 256), 32
+    B = args.batch or 4096                                   # config 5 names 32 768 over 8 GPUs
+    steps, warm = min(args.steps, 20), min(max(args.warmup, 2), 5)
+    net = ConvVAE(B, S, widths, L, -3.0, True)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    params, grads, m, v = net.new_flat(), net.new_flat(), net.new_flat(), net.new_flat()
+    for name, (off, shape) in net.leaves.items():
+        if name.endswith("kernel"):
+            fan = 16 * shape[2] if "Conv" in name and "ConvT" not in name else (4 * shape[3] if "ConvT" in name else shape[0])
+            net.view(params, name).copy_((torch.randn(*shape, generator=g) / math.sqrt(fan)).to(net.device))
+        elif name == "epsilon":
+            net.view(params, name).fill_(1.0)
+    x = torch.rand(B, S, S, 1, generator=g).to(net.device)
+    z1 = torch.randn(B, L, generator=g).to(net.device)
+    z2 = torch.randn(B, S, S, 1, generator=g).to(net.device)
+    step = torch.zeros(1, dtype=torch.int32, device=net.device)
+    for _ in range(warm):
+        net.train_step(params, grads, m, v, step, x, z1, z2, 1e-4)
+    torch.cuda.synchronize()
+    net.eng.profile_begin(max_records=steps * 64)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out4 = net.train_step(params, grads, m, v, step, x, z1, z2, 1e-4)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    rep = net.eng.profile_report()
+    loss = float(out4[0])
+    assert math.isfinite(loss)
+    chans = [1, *widths]
+    macs = sum((S >> (i + 1)) ** 2 * chans[i + 1] * 16 * chans[i] for i in range(4))       # one conv stack, forward, per sample
+    flops = 3 * 2 * (2 * macs + 2 * net.bott * L)                                           # both stacks + the two Dense; fwd + 2 x bwd
+    kernels_s = sum(r["total_ms"] for r in rep.values()) / steps * 1e-3 if rep else None
+    out = {"metric": "ELBO train-step samples/sec", "value": B * steps / elapsed, "unit": "samples/s", "n_gpus": 1, "steps": steps,
+           "warmup": warm, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "C5: conv VAE 64x64x1, 4x4/s2 convs 32|64|128|256, L=32 (BASELINE config 5; no reference counterpart)",
+                      "batch_per_gpu": B, "params": net.n_params, "path": "blocks, launch per layer, eager", "final_loss": loss},
+           "roofline": {"bound": "mfma", "achieved": B * flops / (kernels_s or elapsed / steps) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                        "frac": B * flops / (kernels_s or elapsed / steps) / 1e12 / 2500.0, "traffic": None,
+                        "kernel": "all launches of a step", "kernel_avg_us": (kernels_s or 0.0) * 1e6,
+                        "algorithmic_per_launch": B * flops,
+                        "step_level": {"achieved": B * flops / (elapsed / steps) / 1e12, "frac": B * flops / (elapsed / steps) / 1e12 / 2500.0},
+                        "step_kernels_us": {k: r["total_ms"] / steps * 1e3 for k, r in (rep or {}).items()}},
+           "cpu_baseline": None}
+    print(json.dumps(out), flush=True)
+
+
 def main():
+    if "--workload" in sys.argv and sys.argv[sys.argv.index("--workload") + 1] == "C5":
+        ap = argparse.ArgumentParser()
+        ap.add_argument("--workload"); ap.add_argument("--gpus", type=int, default=1); ap.add_argument("--steps", type=int, default=10)
+        ap.add_argument("--warmup", type=int, default=3); ap.add_argument("--batch", type=int, default=0)
+        ap.add_argument("--no-cpu-baseline", action="store_true")
+        return bench_conv(ap.parse_args())
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=960)

@@ -205,7 +205,7 @@ def test_conv_vae_loss_and_every_gradient_leaf(size, widths, L, B, tdv):
     loss, g = CO.loss_and_grad(cfg, p, x, z1, z2)
     eloss, eg = _bf16_emulation_grads(cfg, p, x, z1, z2)
     net = ConvVAE(B, size, widths, L, -1.5, tdv)
-    assert [n for n, _ in net.leaf_shapes()] == [n for n, _ in cfg.leaves()] and net.P == cfg.n_params()
+    assert [n for n, _ in net.leaf_shapes()] == [n for n, _ in cfg.leaves()] and net.n_params == cfg.n_params()
     params, grads = net.new_flat(), net.new_flat()
     for name in net.leaves:
         net.view(params, name).copy_(_dev(p[name]))

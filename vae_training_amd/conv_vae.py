@@ -33,11 +33,14 @@ class ConvVAE:
         self.eng = Engine(batch, max(size * size, self.bott), latent_dim, (), (), epsilon, tunable_decoder_var, False, device=device,
                           force_generic=True)
         self.device = self.eng.device
-        off, self.leaves = 0, {}
+        # every leaf starts on a 16-byte boundary of the flat buffers (the kernels' 16-byte operand loads); the padding floats stay
+        # zero in parameters, gradients and moments.  n_params counts the leaves only.
+        off, self.leaves, self.n_params = 0, {}, 0
         for name, shape in self.leaf_shapes():
             n = math.prod(shape)
             self.leaves[name] = (off, shape)
-            off += n
+            self.n_params += n
+            off += (n + 3) // 4 * 4
         self.P = off
 
     def leaf_shapes(self):
@@ -88,12 +91,12 @@ class ConvVAE:
             conv2d_bias_grad(d, G(f"Decoder/ConvT{i}/bias"))
             d = conv2d_forward(d, P(f"Decoder/ConvT{i}/kernel"), None, relu=False, mask=inp)      # adjoint of the adjoint + relu below
         d = d.view(B, self.bott)
-        off, _ = self.leaves["Decoder/FC/kernel"]
-        grads[off:off + (L + 1) * self.bott].copy_(e.dense_bwd_dw(samples, d).view(-1))         # [kernel | bias] is contiguous
+        dwb = e.dense_bwd_dw(samples, d)                                                          # [kernel | bias] rows
+        G("Decoder/FC/kernel").copy_(dwb[:L]); G("Decoder/FC/bias").copy_(dwb[L])
         d_s = e.dense_bwd_dx(d, P("Decoder/FC/kernel"))
         e.reparam_bwd(d_s, mu, z1, lv, out=G("epsilon_p"))                                        # d_s becomes d_mu in place
-        off, _ = self.leaves["Encoder/FC/kernel"]
-        grads[off:off + (self.bott + 1) * L].copy_(e.dense_bwd_dw(flat, d_s).view(-1))
+        dwb = e.dense_bwd_dw(flat, d_s)
+        G("Encoder/FC/kernel").copy_(dwb[:self.bott]); G("Encoder/FC/bias").copy_(dwb[self.bott])
         d = e.dense_bwd_dx(d_s, P("Encoder/FC/kernel"), flat, relu=True).view(B, S // 16, S // 16, self.widths[3])
         # ---- backward: encoder
         for i in reversed(range(4)):

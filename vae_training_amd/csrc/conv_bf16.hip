@@ -341,6 +341,11 @@ __global__ __launch_bounds__(CNT) void conv_wgrad_kernel(const ConvWArgs g) {
     const int mc = a_row ? m : 0, tap = mc / g.Cin, ch = mc % g.Cin, kh = tap >> 2, kw = tap & 3;
     const int col = n0 + (t & 127), colc = min(col, g.N - 1);
     float ra[CKU][4], rb[CKU][4];
+    // pixel -> (image, i, j): shifts when the output sizes are powers of two (config 5: 32 / 16 / 8 / 4), divisions otherwise -- 16
+    // pixels per thread and k-tile made the divisions the most expensive thing in this kernel
+    const int hw = g.Ho * g.Wo;
+    const bool pow2 = (hw & (hw - 1)) == 0 && (g.Wo & (g.Wo - 1)) == 0;
+    const int sh_hw = 31 - __builtin_clz(hw), sh_w = 31 - __builtin_clz(g.Wo);
     auto fetch_a = [&](int k0) {
         const int pb = k0 + (CBK / 2) * (t >> 7);
 #pragma unroll
@@ -348,7 +353,8 @@ __global__ __launch_bounds__(CNT) void conv_wgrad_kernel(const ConvWArgs g) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {                  // unconditional at a clamped address, selected afterwards
                 const int p = pb + 4 * u + c, pc = min(p, g.K - 1);
-                const int n = pc / (g.Ho * g.Wo), ij = pc % (g.Ho * g.Wo), yy = 2 * (ij / g.Wo) + kh - 1, xx = 2 * (ij % g.Wo) + kw - 1;
+                const int n = pow2 ? pc >> sh_hw : pc / hw, ij = pow2 ? pc & (hw - 1) : pc % hw;
+                const int yy = 2 * (pow2 ? ij >> sh_w : ij / g.Wo) + kh - 1, xx = 2 * (pow2 ? ij & (g.Wo - 1) : ij % g.Wo) + kw - 1;
                 const bool in = a_row && p < kend && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
                 const int yc = min(max(yy, 0), g.H - 1), xc = min(max(xx, 0), g.W - 1);
                 const float f = g.x[(((long long)n * g.H + yc) * g.W + xc) * g.Cin + ch];
