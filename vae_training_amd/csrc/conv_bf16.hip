@@ -22,7 +22,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 
-constexpr int CBM = 128, CBN = 128, CNT = 256, CBK = 32, CSTR = CBK + 8, CKU = CBK / 8;
+constexpr int CBM = 128, CBN = 128, CNT = 256, CBK = 32, CSTR = CBK + 8, CKU = CBK / 8;     // (64-deep k-tiles measured slower: forward 1.1 -> 2.0 ms, kernel gradient unchanged)
 
 struct ConvArgs {
     const float* x; const float* w; const float* bias; const float* mask; float* y;
