@@ -197,7 +197,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
     // Register staging: one k-tile ahead, or TWO for the tall-skinny streaming shape (128 x 32 tile, a few hundred
     // workgroups = one per CU: a single 16 KB tile in flight per CU cannot cover HBM latency).
     constexpr bool DEEP = (WM == 4 && EPI != EPI_DW);
-    constexpr int NSET = DEEP ? 2 : 1;
+    constexpr int NSET = DEEP ? 2 : 1;      // (four k-tiles in flight measured slower than two: C4's encoder forward 208 -> 233 us, dX 160 -> 171)
     float ra[NSET][(BM * BK / 4 + NT - 1) / NT][4], rb[NSET][(BN * BK / 4 + NT - 1) / NT][4];
     // does this workgroup's tile lie fully inside each operand (rows / columns; the k range is checked per k-tile)?
     const bool a_in = a_vec && (A_KCONT ? m0 + BM <= g.M : m0 + BM <= g.a_mem);
@@ -233,11 +233,13 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[jn], acc[i][jn], 0, 0, 0);
         }
     };
-    if (kbeg < kend) fetch(kbeg, 0);
-    if (DEEP && kbeg + BK < kend) fetch(kbeg + BK, 1);
+#pragma unroll
+    for (int s2 = 0; s2 < NSET; ++s2)
+        if (kbeg + s2 * BK < kend) fetch(kbeg + s2 * BK, s2);
     for (int k0 = kbeg; k0 < kend; k0 += NSET * BK) {
-        stage_and_multiply(k0, 0);
-        if (DEEP && k0 + BK < kend) stage_and_multiply(k0 + BK, 1);
+#pragma unroll
+        for (int s2 = 0; s2 < NSET; ++s2)
+            if (k0 + s2 * BK < kend) stage_and_multiply(k0 + s2 * BK, s2);
     }
     // C/D map of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float e_mse = 0.f, e_deps = 0.f, e_inv_var = 0.f, e_sigma = 0.f, e_dscale = 0.f;
