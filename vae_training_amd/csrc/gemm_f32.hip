@@ -351,6 +351,8 @@ static int launch(const GemmArgs& g, int splits, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return VAEK_OK;
     constexpr bool kAllF32 = sizeof(TA) == 4 && sizeof(TB) == 4 && sizeof(TC) == 4 && sizeof(TX) == 4;
     // skinny shapes stream a long K past a small output: a 32-deep k-tile halves their barriers per byte
+    // (64-deep k-tiles for the long-row skinny forward / dX, 256-byte row pieces, measured slower again in round 2: C4's encoder
+    // forward 208 -> 250 us, dX 160 -> 217)
     if (g.N <= 32) return launch_shape<TA, TB, TC, TX, A_KCONT, B_KCONT, EPI, 4, 1, 32>(g, splits, st);     // skinny output: 128 x 32
     if (g.M <= 32) return launch_shape<TA, TB, TC, TX, A_KCONT, B_KCONT, EPI, 1, 4, 32>(g, splits, st);     // skinny M:      32 x 128
     // wide layers: 128 x 128 (each wave 2 x 2 MFMA tiles) halves the operand bytes pulled through L2 per flop -- at
