@@ -170,6 +170,25 @@ def _steps_worker(rank, world, port, q):
         eng.train_steps(params, grads, m, v, step, batches[:4], lr)                # two launches: 4 + 3 steps
         eng.train_steps(params, grads, m, v, step, batches[4:], lr)
         torch.cuda.synchronize()
+        # the stand-alone all-reduce keeps its epoch on the device: captured once, replayed three times, right every time
+        import ctypes as C
+        from vae_training_amd import _lib
+        buf = torch.zeros(300, device="cuda")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=side):
+                _lib.check(eng.lib.vaek_comm_allreduce(eng.h, C.c_void_p(buf.data_ptr()), 300, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.current_stream().wait_stream(side)
+        for rep in range(3):
+            buf.copy_(torch.arange(300, device="cuda") * 0.5 + (rank + 1) * (rep + 1))
+            dist.barrier()
+            gr.replay()
+            torch.cuda.synchronize()
+            want_buf = torch.arange(300, device="cuda") * 0.5 * world + sum(r + 1 for r in range(world)) * (rep + 1)
+            assert torch.equal(buf, want_buf.to(torch.float32)), (rep, buf[:3], want_buf[:3])
+        assert not ex.timed_out()
         got = ring.cpu().numpy()[:steps].astype(np.float64)
         worst = float(np.max(np.abs(got - np.array(want)) / np.abs(want)))
         perr = float(np.max(np.abs(params.cpu().numpy().astype(np.float64) - O.flatten(cfg, p))))

@@ -10,11 +10,15 @@ namespace vaek {
 
 static size_t granules_per_region(const vaek_ctx* c) { return 2ull * c->cfg.world * c->comm.ng; }
 
-__global__ __launch_bounds__(256) void p2p_allreduce_kernel(CommDev c, float* buf, long long n, unsigned epoch) {
+// The epoch of a stand-alone all-reduce lives on the DEVICE (a word of the status line, behind the give-up flag): every workgroup
+// reads it, a one-thread kernel behind the exchange advances it -- so the call can be captured into a hipGraph and replayed (a
+// host-side counter would be frozen into the captured kernel arguments).  Every rank makes the same calls: the counters agree.
+__global__ __launch_bounds__(256) void p2p_allreduce_kernel(CommDev c, float* buf, long long n, const unsigned* epoch_dev) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    buf[i] = comm_exchange_sum(c, epoch, (int)i, buf[i]);
+    buf[i] = comm_exchange_sum(c, epoch_dev[0] + 1u, (int)i, buf[i]);
 }
+__global__ void p2p_epoch_bump_kernel(unsigned* epoch_dev) { epoch_dev[0] += 1u; }
 
 CommDev comm_dev(const vaek_ctx* c, int region) {
     CommDev d{};
@@ -116,11 +120,14 @@ int vaek_comm_allreduce(vaek_ctx* ctx, float* buf, int64_t n, void* stream) {
     if (!ctx->comm.ready) { set_error("communicator not initialised"); return VAEK_ERR_COMM; }
     if (n > ctx->comm.ng) { set_error("vaek_comm_allreduce: n=%lld exceeds the exchange buffer (%d)", (long long)n, ctx->comm.ng); return VAEK_ERR_COMM; }
     if (n == 0) return VAEK_OK;
-    const unsigned epoch = ++ctx->comm.epoch;       // host-side counter: not for graph capture (the fused
-                                                    // train step uses the device Adam step instead)
-    ProfScope ps("p2p_allreduce", (hipStream_t)stream);
-    launch_k(ps, p2p_allreduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       comm_dev(ctx, 1), buf, (long long)n, epoch);
+    const CommDev d = comm_dev(ctx, 1);
+    unsigned* epoch_dev = d.status + 1;               // zeroed with the buffer at vaek_comm_create
+    {
+        ProfScope ps("p2p_allreduce", (hipStream_t)stream);
+        launch_k(ps, p2p_allreduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d, buf, (long long)n,
+                 (const unsigned*)epoch_dev);
+    }
+    hipLaunchKernelGGL(p2p_epoch_bump_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, epoch_dev);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
 }
