@@ -193,7 +193,8 @@ def _bf16_emulation_grads(cfg, p, x, z1, z2):
     return loss.item(), {k: t.grad.numpy() for k, t in tp.items()}
 
 
-@pytest.mark.parametrize("size,widths,L,B,tdv", [(16, (4, 8, 8, 16), 5, 6, True), (32, (8, 16, 16, 32), 7, 4, False), (64, (4, 8, 8, 16), 8, 3, True)])
+@pytest.mark.parametrize("size,widths,L,B,tdv", [(16, (4, 8, 8, 16), 5, 6, True), (32, (8, 16, 16, 32), 7, 4, False), (64, (4, 8, 8, 16), 8, 3, True),
+                                                 (64, (32, 64, 128, 256), 32, 2, True)])        # the last: BASELINE config 5's own widths
 def test_conv_vae_loss_and_every_gradient_leaf(size, widths, L, B, tdv):
     """The whole convolutional VAE -- forward, ELBO, backward assembled from the library's blocks -- against (i) the
     same arithmetic emulated in float64 with the convolution operands rounded to bf16 where the kernels round them (tight: the
