@@ -447,12 +447,16 @@ struct HsDwArgs {
     const __bf16* X; const __bf16* dY; float* slab;   // X [rows, M] (ldx), dY [rows, N] (ldy), slab[split][(M + 1) x N]
     int rows, M, N, ldx, ldy, rows_per_split; long long slab_stride;
     int tiles_m, tiles_n;
+    // CONV (the kernel gradient of a 4x4 / stride 2 / pad 1 convolution, conv_bf16.hip): the "rows" are the output pixels of an
+    // NHWC image batch, column m = (kh, kw, c) of row p is x[n, 2 i + kh - 1, 2 j + kw - 1, c] -- gathered by the loader, 8
+    // channels (16 bytes) per lane, from `zeros` where the tap falls outside the image; Ho, Wo powers of two, Cin a multiple of 8
+    int H, W, Cin, sh_hw, sh_w; const __bf16* zeros;
 };
 
 // LDS image of a BK-row(k) x 128-feature tile: 256-byte rows, 16-byte chunk ch of row k at chunk position
 // ch ^ (((k & 3) << 2) | ((k >> 2) & 3)): the 32 lanes of a ds_read_b64_tr_b16 half (4 k-rows x 2 blocks of 16
 // features) then cover the 256-byte bank row exactly.
-template <int BK, int NS>
+template <int BK, int NS, bool CONV = false>
 __global__ __launch_bounds__(256) void hs_tn_kernel(const HsDwArgs g) {
     constexpr int BM = 128, BN = 128, T_BYTES = BK * 256, BUF = 2 * T_BYTES;
     constexpr int PASSES = BK / 16, P = 2 * PASSES;           // staging passes per operand tile; loads per k-tile and wave
@@ -477,12 +481,29 @@ __global__ __launch_bounds__(256) void hs_tn_kernel(const HsDwArgs g) {
         a_col[i] = min(m0 + ch * 8, g.M - 8);        // a partial last tile re-reads valid columns; those outputs are not stored
         b_col[i] = min(n0 + ch * 8, g.N - 8);
     }
+    // CONV: this thread's chunk of 8 columns is 8 channels of ONE tap, fixed for the whole kernel
+    int c_dy[PASSES], c_dx[PASSES], c_ch[PASSES];
+    if (CONV) {
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int tap = a_col[i] / g.Cin;
+            c_dy[i] = (tap >> 2) - 1; c_dx[i] = (tap & 3) - 1; c_ch[i] = a_col[i] % g.Cin;
+        }
+    }
     auto stage = [&](int k0, int slot) {
         char* base = smem + slot * BUF;
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
             const long long krow = min(k0 + s_row[i], g.rows - 1);
-            glds16(g.X + krow * g.ldx + a_col[i], base + (i * 256 + wv * 64) * 16);
+            if (CONV) {
+                const int pix = (int)krow, n = pix >> g.sh_hw, ij = pix & ((1 << g.sh_hw) - 1);
+                const int yy = 2 * (ij >> g.sh_w) + c_dy[i], xx = 2 * (ij & ((1 << g.sh_w) - 1)) + c_dx[i];
+                const bool in = yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+                const __bf16* src = in ? g.X + (((long long)n * g.H + yy) * g.W + xx) * g.Cin + c_ch[i] : g.zeros;
+                glds16(src, base + (i * 256 + wv * 64) * 16);
+            } else {
+                glds16(g.X + krow * g.ldx + a_col[i], base + (i * 256 + wv * 64) * 16);
+            }
             glds16(g.dY + krow * g.ldy + b_col[i], base + T_BYTES + (i * 256 + wv * 64) * 16);
         }
     };
@@ -692,6 +713,46 @@ int launch_hs_dw(const __bf16* x, const __bf16* dy, float* slab0, int64_t slab_s
     }
     ProfScope ps("gemm_bf16s_dw", st);
     launch_k(ps, v.fn, dim3((unsigned)(g.tiles_m * g.tiles_n * S)), dim3(256), v.lds, st, g);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+// float32 -> bf16 copies (the convolution's kernel gradient reads its two tensors through the bf16-storage loader)
+__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long long n, __bf16* zero8) {
+    if (zero8 && blockIdx.x == 0 && threadIdx.x < 8) zero8[threadIdx.x] = (__bf16)0.f;       // the loader's 16-byte page of zeros
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const float4 a = *reinterpret_cast<const float4*>(src + i), b = *reinterpret_cast<const float4*>(src + i + 4);
+        const bf16x8 o = {(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w, (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
+        *reinterpret_cast<bf16x8*>(dst + i) = o;
+    } else {
+        for (long long k = i; k < n; ++k) dst[k] = (__bf16)src[k];
+    }
+}
+int launch_cvt_bf16(const float* src, __bf16* dst, int64_t n, __bf16* zero8, hipStream_t st) {
+    if (n <= 0) return VAEK_OK;
+    ProfScope ps("cvt_bf16", st);
+    launch_k(ps, cvt_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256 + 1)), dim3(256), 0, st, src, dst, (long long)n, zero8);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+// kernel gradient of a 4x4 / stride 2 / pad 1 convolution on bf16 copies: slab[s][(16 Cin + 1) x Cout] (row 16 Cin: the bias gradient)
+int launch_hs_conv_dw(const __bf16* x, const __bf16* dy, const __bf16* zeros, float* slab0, int64_t slab_stride, int S, int rows_per_split,
+                      int batch, int H, int W, int Cin, int Cout, hipStream_t st) {
+    const int Ho = H / 2, Wo = W / 2, hw = Ho * Wo;
+    if (Cin % 8 || Cout % 8 || (hw & (hw - 1)) || (Wo & (Wo - 1))) { set_error("conv dW on the bf16-storage loader: unsupported shape"); return VAEK_ERR_INVALID; }
+    HsDwArgs g{};
+    g.X = x; g.dY = dy; g.slab = slab0; g.rows = batch * hw; g.M = 16 * Cin; g.N = Cout; g.ldx = 0; g.ldy = Cout;
+    g.rows_per_split = rows_per_split; g.slab_stride = slab_stride;
+    g.tiles_m = (g.M + 127) / 128; g.tiles_n = (g.N + 127) / 128;
+    g.H = H; g.W = W; g.Cin = Cin; g.sh_hw = 31 - __builtin_clz(hw); g.sh_w = 31 - __builtin_clz(Wo); g.zeros = zeros;
+    const auto fn = hs_tn_kernel<64, 2, true>;
+    const size_t lds = 2 * 2 * 64 * 256;
+    static thread_local bool attr_set = false;
+    if (!attr_set) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+    ProfScope ps("conv_wgrad_bf16s", st);
+    launch_k(ps, fn, dim3((unsigned)(g.tiles_m * g.tiles_n * S)), dim3(256), lds, st, g);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
 }
