@@ -8,5 +8,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ks_$NAME -
 cd $R
 F=$(find gpurun_out/ks_$NAME -name "*kernel_stats.csv" | head -1)
 cp "$F" gpurun_out/${NAME}_kernel_stats.csv
-tail -1 gpurun_out/ks_$NAME.log | cut -c1-400
+grep '^{"metric' gpurun_out/ks_$NAME.log | tail -1 > gpurun_out/${NAME}_line.json
+cut -c1-400 gpurun_out/${NAME}_line.json
 head -8 gpurun_out/${NAME}_kernel_stats.csv | cut -c1-200

@@ -416,6 +416,107 @@ static int conv_wgrad_splits(long long pixels, int M, int N) {
     return (int)std::min(S, 4096ll);
 }
 
+// ---- the one-channel layers (the first convolution, the last transposed convolution and their gradients): streaming kernels --------
+// 16 or 128 multiply-adds per output value against 4 to 128 bytes of traffic: HBM-bound, nothing for the matrix cores.  Exact f32.
+struct ThinArgs {
+    const float* x; const float* w; const float* bias; const float* mask; float* y;
+    int B, H, W, C, Ho, Wo; long long pixels;          // C: the wide side's channel count
+};
+// forward, C_in = 1: y[p, o] = act(b[o] + sum_taps x_window[p, tap] K[tap, o]).  Thread = (pixel lane, o); C | 256.
+__global__ __launch_bounds__(256) void thin_conv_fwd_kernel(const ThinArgs g, const int relu) {
+    const int C = g.C, o = threadIdx.x % C, pl = threadIdx.x / C, ppb = 256 / C;
+    float wk[16];
+#pragma unroll
+    for (int tp = 0; tp < 16; ++tp) wk[tp] = g.w[tp * C + o];
+    const float b = g.bias ? g.bias[o] : 0.f;
+    for (long long p = (long long)blockIdx.x * ppb + pl; p < g.pixels; p += (long long)gridDim.x * ppb) {
+        const int n = (int)(p / (g.Ho * g.Wo)), ij = (int)(p % (g.Ho * g.Wo)), y0 = 2 * (ij / g.Wo) - 1, x0 = 2 * (ij % g.Wo) - 1;
+        const float* img = g.x + (long long)n * g.H * g.W;
+        float acc = b;
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+                const int yy = y0 + kh, xx = x0 + kw;
+                const bool in = yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+                const float v = img[(long long)min(max(yy, 0), g.H - 1) * g.W + min(max(xx, 0), g.W - 1)];
+                acc = fmaf(in ? v : 0.f, wk[kh * 4 + kw], acc);
+            }
+        if (relu) acc = fmaxf(acc, 0.f);
+        if (g.mask) acc = g.mask[p * C + o] > 0.f ? acc : 0.f;
+        g.y[p * C + o] = acc;
+    }
+}
+// transposed forward, C_out = 1: out[n, P, Q] = act(b + sum over the 2 x 2 contributing taps and c of y[n, i, j, c] K[kh, kw, 0, c]).
+// Thread = one output pixel; the 16 x C kernel slice in LDS; C % 4 == 0, C <= 256.
+__global__ __launch_bounds__(256) void thin_conv_t_fwd_kernel(const ThinArgs g, const int relu) {
+    __shared__ __attribute__((aligned(16))) float ks[16 * 256];
+    const int C = g.C;
+    for (int e = threadIdx.x; e < 16 * C; e += 256) ks[e] = g.w[e];
+    __syncthreads();
+    const float b = g.bias ? g.bias[0] : 0.f;
+    const int Hout = 2 * g.H, Wout = 2 * g.W;           // here H, W are the INPUT sizes
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < g.pixels; p += (long long)gridDim.x * 256) {
+        const int n = (int)(p / ((long long)Hout * Wout)), PQ = (int)(p % ((long long)Hout * Wout)), P = PQ / Wout, Q = PQ % Wout;
+        const int pp = P & 1, qq = Q & 1;
+        float acc = b;
+#pragma unroll
+        for (int th = 0; th < 2; ++th)
+#pragma unroll
+            for (int tw = 0; tw < 2; ++tw) {
+                const int i = (P >> 1) + pp - th, j = (Q >> 1) + qq - tw, kh = 1 - pp + 2 * th, kw = 1 - qq + 2 * tw;
+                const bool in = i >= 0 && i < g.H && j >= 0 && j < g.W;
+                const float4* src = reinterpret_cast<const float4*>(g.x + (((long long)n * g.H + min(max(i, 0), g.H - 1)) * g.W + min(max(j, 0), g.W - 1)) * C);
+                const float4* kk = reinterpret_cast<const float4*>(ks + (kh * 4 + kw) * C);
+                float part = 0.f;
+                for (int c4 = 0; c4 < C / 4; ++c4) {
+                    const float4 v = src[c4], k4 = kk[c4];
+                    part = fmaf(v.x, k4.x, part); part = fmaf(v.y, k4.y, part); part = fmaf(v.z, k4.z, part); part = fmaf(v.w, k4.w, part);
+                }
+                acc += in ? part : 0.f;
+            }
+        if (relu) acc = fmaxf(acc, 0.f);
+        if (g.mask) acc = g.mask[p] > 0.f ? acc : 0.f;
+        g.y[p] = acc;
+    }
+}
+// kernel gradient with a one-channel gathered tensor: part[block][tap or 16 = bias][o] = sum over the block's pixels of
+// x_window[p, tap] dy[p, o]; thread = (pixel lane, o), the lanes of a block meet through LDS, a fixed-order sum over the blocks follows
+__global__ __launch_bounds__(256) void thin_conv_wgrad_kernel(const ThinArgs g, float* part) {
+    __shared__ float red[256 * 17];
+    const int C = g.C, o = threadIdx.x % C, pl = threadIdx.x / C, ppb = 256 / C;
+    float acc[17];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) acc[k] = 0.f;
+    const long long per = (g.pixels + gridDim.x - 1) / gridDim.x, p0 = blockIdx.x * per, p1 = min(g.pixels, p0 + per);
+    for (long long p = p0 + pl; p < p1; p += ppb) {
+        const int n = (int)(p / (g.Ho * g.Wo)), ij = (int)(p % (g.Ho * g.Wo)), y0 = 2 * (ij / g.Wo) - 1, x0 = 2 * (ij % g.Wo) - 1;
+        const float* img = g.x + (long long)n * g.H * g.W;
+        const float d = g.mask[p * C + o];               // (mask: the C-channel tensor here)
+        acc[16] += d;
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+                const int yy = y0 + kh, xx = x0 + kw;
+                const bool in = yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+                const float v = img[(long long)min(max(yy, 0), g.H - 1) * g.W + min(max(xx, 0), g.W - 1)];
+                acc[kh * 4 + kw] = fmaf(in ? v : 0.f, d, acc[kh * 4 + kw]);
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 17; ++k) red[(k * ppb + pl) * C + o] = acc[k];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 17 * C; e += 256) {
+        const int k = e / C, oo = e % C;
+        float sum = 0.f;
+        for (int l = 0; l < ppb; ++l) sum += red[(k * ppb + l) * C + oo];
+        part[(long long)blockIdx.x * 17 * C + e] = sum;
+    }
+}
+static bool thin_channels_ok(int c) { return c >= 1 && c <= 256 && 256 % c == 0; }
+constexpr int kThinWgradBlocks = 1024;
+
 }  // namespace vaek
 
 using namespace vaek;
@@ -447,6 +548,7 @@ extern "C" int vaek_conv2d_weight_grad_workspace(int32_t batch, int32_t height, 
     const int M = 16 * c_in + 1;
     const ConvWFast f = conv_wgrad_fast(batch, height, width, c_in, c_out);
     *bytes = f.ok ? f.bytes : (size_t)conv_wgrad_splits(pixels, M, c_out) * M * c_out * sizeof(float);
+    if (c_in == 1 && thin_channels_ok(c_out)) *bytes = std::max(*bytes, (size_t)kThinWgradBlocks * 17 * c_out * sizeof(float));
     return VAEK_OK;
 }
 
@@ -462,6 +564,21 @@ extern "C" int vaek_conv2d_weight_grad(const float* x, const float* dy, float* d
     const long long pixels = (long long)batch * g.Ho * g.Wo;
     if (pixels > 0x7fffffffll) { set_error("vaek_conv2d_weight_grad: too many pixels"); return VAEK_ERR_INVALID; }
     hipStream_t st0 = (hipStream_t)stream;
+    if (c_in == 1 && thin_channels_ok(c_out)) {           // one-channel gathered tensor: a streaming kernel, exact f32
+        ThinArgs ta{};
+        ta.x = x; ta.mask = dy;
+        ta.B = batch; ta.H = height; ta.W = width; ta.C = c_out; ta.Ho = g.Ho; ta.Wo = g.Wo; ta.pixels = pixels;
+        float* part = static_cast<float*>(workspace);
+        const int nb = (int)std::min<long long>(kThinWgradBlocks, (pixels + 255) / 256);
+        {
+            ProfScope ps("conv_wgrad_thin", st0);
+            launch_k(ps, thin_conv_wgrad_kernel, dim3(nb), dim3(256), 0, st0, ta, part);
+            VAEK_HIP_CHECK(hipGetLastError());
+        }
+        int rc = launch_sum_slabs(part, (int64_t)17 * c_out, nb, dw, (int64_t)16 * c_out, st0);
+        if (rc == VAEK_OK && dbias) rc = launch_sum_slabs(part + 16 * c_out, (int64_t)17 * c_out, nb, dbias, c_out, st0);
+        return rc;
+    }
     const ConvWFast f = conv_wgrad_fast(batch, height, width, c_in, c_out);
     if (f.ok) {
         char* ws = static_cast<char*>(workspace);
@@ -517,6 +634,15 @@ extern "C" int vaek_conv2d_transpose_forward(const float* y, const float* w, con
     g.B = batch; g.h = height; g.w_in = width; g.Cin = c_in; g.Cout = c_out;
     const long long M = (long long)batch * height * width;
     if (M > 0x7fffffffll || (M + CBM - 1) / CBM > 65535) { set_error("vaek_conv2d_transpose_forward: too many pixels"); return VAEK_ERR_INVALID; }
+    if (c_out == 1 && c_in % 4 == 0 && c_in <= 256 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+        ThinArgs ta{};                                    // the last layer's shape: a streaming kernel, exact f32
+        ta.x = y; ta.w = w; ta.bias = bias; ta.mask = mask; ta.y = out;
+        ta.B = batch; ta.H = height; ta.W = width; ta.C = c_in; ta.pixels = 4 * M;
+        ProfScope ps("conv_t_fwd_thin", (hipStream_t)stream);
+        launch_k(ps, thin_conv_t_fwd_kernel, dim3((unsigned)std::min<long long>(16384, (4 * M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
+        VAEK_HIP_CHECK(hipGetLastError());
+        return VAEK_OK;
+    }
     g.M = (int)M; g.N = c_out; g.K = 4 * c_in; g.relu = relu;
     ProfScope ps("conv_t_fwd_bf16", (hipStream_t)stream);
     launch_k(ps, conv_t_fwd_kernel, dim3((g.N + CBN - 1) / CBN, (g.M + CBM - 1) / CBM, 4), dim3(CNT), 0, (hipStream_t)stream, g);
@@ -535,6 +661,15 @@ extern "C" int vaek_conv2d_forward(const float* x, const float* w, const float* 
     g.B = batch; g.H = height; g.W = width; g.Cin = c_in; g.Cout = c_out; g.Ho = height / 2; g.Wo = width / 2;
     const long long M = (long long)batch * g.Ho * g.Wo;
     if (M > 0x7fffffffll || (M + CBM - 1) / CBM > 65535) { set_error("vaek_conv2d_forward: too many output pixels"); return VAEK_ERR_INVALID; }
+    if (c_in == 1 && thin_channels_ok(c_out)) {           // the first layer's shape: a streaming kernel, exact f32
+        ThinArgs ta{};
+        ta.x = x; ta.w = w; ta.bias = bias; ta.mask = mask; ta.y = y;
+        ta.B = batch; ta.H = height; ta.W = width; ta.C = c_out; ta.Ho = g.Ho; ta.Wo = g.Wo; ta.pixels = M;
+        ProfScope ps("conv_fwd_thin", (hipStream_t)stream);
+        launch_k(ps, thin_conv_fwd_kernel, dim3((unsigned)std::min<long long>(8192, (M * c_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
+        VAEK_HIP_CHECK(hipGetLastError());
+        return VAEK_OK;
+    }
     g.M = (int)M; g.N = c_out; g.K = 16 * c_in; g.relu = relu;
     ProfScope ps("conv_fwd_bf16", (hipStream_t)stream);
     launch_k(ps, conv_fwd_kernel, dim3((g.N + CBN - 1) / CBN, (g.M + CBM - 1) / CBM), dim3(CNT), 0, (hipStream_t)stream, g);
