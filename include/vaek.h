@@ -241,14 +241,20 @@ int vaek_train_steps_status(vaek_ctx* ctx, void* workspace, int32_t* gave_up);
  *   y[n, i, j, o] = act(bias[o] + sum_{kh, kw, c} x[n, 2 i + kh - 1, 2 j + kw - 1, c] * w[kh, kw, c, o]),  y: [batch, height/2, width/2, c_out].
  * No context needed.  With the two entry points below every product of both layer kinds' forward and backward passes exists; the
  * convolutional VAE's train step is not assembled yet. */
+/* `workspace`: vaek_conv2d_forward_workspace bytes (transposed = 0 / 1 for the two entry points; 0 bytes = none needed), 16-byte
+ * aligned, or NULL.  With a workspace, c_in a power of two (>= 8; >= 16 transposed), c_out a multiple of 32 and 16-byte aligned
+ * tensors the layer runs on bf16 copies through the LDS-DMA GEMM (the same bf16 products, several times faster); otherwise, and
+ * always for NULL, the register-staged kernel.  Layers with ONE channel on the thin side (c_in = 1 here, c_out = 1 transposed)
+ * are streaming float32 kernels -- exact, no bf16 rounding. */
+int vaek_conv2d_forward_workspace(int32_t batch, int32_t height, int32_t width, int32_t c_in, int32_t c_out, int32_t transposed, size_t* bytes);
 int vaek_conv2d_forward(const float* x, const float* w, const float* bias, const float* mask, float* y, int32_t batch, int32_t height,
-                        int32_t width, int32_t c_in, int32_t c_out, int32_t relu, void* stream);   /* mask: as below; NULL = none */
+                        int32_t width, int32_t c_in, int32_t c_out, int32_t relu, void* workspace, void* stream);   /* mask: as below; NULL = none */
 /* The transposed convolution of the same specification = the adjoint of vaek_conv2d_forward with the SAME kernel array
  * (oracle: conv_t_fwd): y [batch, height, width, c_in], w [4][4][c_out][c_in] (the HWIO kernel of the convolution it is the adjoint
  * of), out [batch, 2 height, 2 width, c_out] = act(bias + ...).  It is also the convolution's input gradient (y := dL/d output, bias
  * NULL); `mask` (NULL or a tensor of out's shape) multiplies the result by [mask > 0] -- the relu of the layer below. */
 int vaek_conv2d_transpose_forward(const float* y, const float* w, const float* bias, const float* mask, float* out, int32_t batch,
-                                  int32_t height, int32_t width, int32_t c_in, int32_t c_out, int32_t relu, void* stream);
+                                  int32_t height, int32_t width, int32_t c_in, int32_t c_out, int32_t relu, void* workspace, void* stream);
 /* Kernel gradient of vaek_conv2d_forward (oracle: conv_bwd): dw[kh, kw, c, o] = sum_{n, i, j} x[n, 2 i + kh - 1, 2 j + kw - 1, c] *
  * dy[n, i, j, o], dbias[o] = sum dy (NULL: not wanted); x [batch, height, width, c_in], dy [batch, height/2, width/2, c_out].
  * Batch-split slabs in `workspace` (vaek_conv2d_weight_grad_workspace bytes) + a fixed-order sum: bitwise repeatable.  With

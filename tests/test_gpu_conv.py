@@ -23,6 +23,9 @@ def _dev(a):
     (2, 6, 3, 7, True),            # channel count off the 4-grid: the scalar gather; non-square-power sizes
     (1, 2, 8, 130, False),         # one output pixel per image; more than one column tile
     (37, 8, 12, 16, True),         # 592 output pixels: a partial last row tile
+    (3, 10, 8, 32, True),          # the LDS-DMA form (power-of-two c_in, c_out % 32 == 0): fewer rows than one tile, 32-column tiles
+    (5, 6, 16, 96, False),         # three 32-column tiles
+    (9, 12, 32, 192, True),        # 64-column tiles, a partial last row tile
 ])
 def test_conv2d_forward_matches_the_oracle(B, S, cin, cout, relu):
     from vae_training_amd.conv import conv2d_forward
@@ -43,6 +46,18 @@ def test_conv2d_forward_matches_the_oracle(B, S, cin, cout, relu):
     assert np.array_equal(got, again)
 
 
+def test_lds_dma_and_register_staged_forms_agree():
+    """Same bf16 products, float32 accumulation in a different order: 1e-5 of the result's scale."""
+    from vae_training_amd.conv import conv2d_forward, conv2d_transpose_forward
+    torch.manual_seed(1)
+    x = torch.randn(6, 16, 16, 32, device="cuda"); K = torch.randn(4, 4, 32, 64, device="cuda") / 22.6; b = torch.randn(64, device="cuda")
+    a, c = conv2d_forward(x, K, b, True), conv2d_forward(x, K, b, True, fast=False)
+    assert float((a - c).abs().max()) <= 1e-5 * float(c.abs().max())
+    y = torch.randn(6, 8, 8, 64, device="cuda"); m = torch.randn(6, 16, 16, 32, device="cuda")
+    a, c = conv2d_transpose_forward(y, K, None, False, m), conv2d_transpose_forward(y, K, None, False, m, fast=False)
+    assert float((a - c).abs().max()) <= 1e-5 * float(c.abs().max())
+
+
 def test_conv2d_forward_rejects_odd_sizes():
     from vae_training_amd._lib import VaekError
     from vae_training_amd.conv import conv2d_forward
@@ -58,6 +73,9 @@ def test_conv2d_forward_rejects_odd_sizes():
     (3, 5, 4, 5, False, True),         # odd sizes, ragged rows and columns, the input-gradient form with a relu mask
     (2, 3, 3, 7, True, False),         # channel count off the 4-grid: the scalar gathers
     (1, 1, 8, 130, False, True),       # one input pixel; more than one column tile
+    (3, 5, 16, 32, False, True),       # the LDS-DMA form: odd sizes, ragged rows, mask
+    (2, 3, 32, 96, True, False),
+    (1, 1, 64, 64, True, True),        # one input pixel: every neighbour tap off the image
 ])
 def test_conv2d_transpose_forward_matches_the_oracle(B, h, cin, cout, relu, masked):
     from vae_training_amd.conv import conv2d_transpose_forward
@@ -267,7 +285,7 @@ def _checked_conv_calls(monkeypatch, log):
         ref = torch.nn.grad.conv2d_weight(r(nchw(x)), (dy.shape[3], x.shape[3], 4, 4), r(nchw(dy)), stride=2, padding=1).permute(2, 3, 1, 0)
         log.append(("kernel gradient", tuple(x.shape), rel(dw.reshape(ref.shape), ref)))
         if db is not None:
-            log.append(("bias gradient", tuple(x.shape), rel(db, dy.double().cpu().sum(dim=(0, 1, 2)))))
+            log.append(("bias gradient", tuple(x.shape), rel(db, r(dy.double().cpu()).sum(dim=(0, 1, 2)))))      # a ones row of the same bf16 product
         return dw, db
 
     monkeypatch.setattr(CV, "conv2d_forward", fwd)

@@ -7,7 +7,15 @@ import torch
 from . import _lib
 
 
-def conv2d_forward(x, w, bias=None, relu=False, mask=None, out=None):
+def _forward_workspace(lib, B, H, W, Cin, Cout, transposed, device, fast):
+    if not fast:
+        return None
+    nbytes = C.c_size_t()
+    _lib.check(lib.vaek_conv2d_forward_workspace(B, H, W, Cin, Cout, int(transposed), C.byref(nbytes)))
+    return torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=device) if nbytes.value else None
+
+
+def conv2d_forward(x, w, bias=None, relu=False, mask=None, out=None, fast=True):
     """4 x 4 / stride 2 / pad 1 convolution: x [B, H, W, Cin] float32 NHWC, w [4, 4, Cin, Cout] HWIO -> [B, H/2, W/2, Cout]
     (vaek_conv2d_forward: implicit GEMM on the bf16 matrix cores, float32 accumulation)."""
     lib = _lib.load()
@@ -18,12 +26,13 @@ def conv2d_forward(x, w, bias=None, relu=False, mask=None, out=None):
     y = torch.empty(B, H // 2, W // 2, Cout, dtype=torch.float32, device=x.device) if out is None else out
     assert mask is None or (mask.shape == y.shape and mask.is_contiguous())
     p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
-    _lib.check(lib.vaek_conv2d_forward(p(x), p(w), p(bias), p(mask), p(y), B, H, W, Cin, Cout, int(bool(relu)),
+    ws = _forward_workspace(lib, B, H, W, Cin, Cout, False, x.device, fast)      # fast=False: the register-staged kernel
+    _lib.check(lib.vaek_conv2d_forward(p(x), p(w), p(bias), p(mask), p(y), B, H, W, Cin, Cout, int(bool(relu)), p(ws),
                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     return y
 
 
-def conv2d_transpose_forward(y, w, bias=None, relu=False, mask=None):
+def conv2d_transpose_forward(y, w, bias=None, relu=False, mask=None, fast=True):
     """The adjoint of conv2d_forward with the same kernel array: y [B, h, w, Cin], w [4, 4, Cout, Cin] -> [B, 2 h, 2 w, Cout]
     (vaek_conv2d_transpose_forward).  With bias=None it is the convolution's input gradient; `mask` applies the relu of the layer
     below ([mask > 0])."""
@@ -35,7 +44,8 @@ def conv2d_transpose_forward(y, w, bias=None, relu=False, mask=None):
     out = torch.empty(B, 2 * h, 2 * wd, Cout, dtype=torch.float32, device=y.device)
     assert mask is None or (mask.shape == out.shape and mask.is_contiguous())
     p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
-    _lib.check(lib.vaek_conv2d_transpose_forward(p(y), p(w), p(bias), p(mask), p(out), B, h, wd, Cin, Cout, int(bool(relu)),
+    ws = _forward_workspace(lib, B, h, wd, Cin, Cout, True, y.device, fast)
+    _lib.check(lib.vaek_conv2d_transpose_forward(p(y), p(w), p(bias), p(mask), p(out), B, h, wd, Cin, Cout, int(bool(relu)), p(ws),
                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     return out
 

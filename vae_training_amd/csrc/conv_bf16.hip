@@ -514,7 +514,100 @@ __global__ __launch_bounds__(256) void thin_conv_wgrad_kernel(const ThinArgs g, 
         part[(long long)blockIdx.x * 17 * C + e] = sum;
     }
 }
+// The same two kernels for C a multiple of 8 that divides 256: thread = (pixel, group of 8 channels) -- the 16 window loads feed 128
+// multiply-adds instead of 16, 32-byte runs per lane on the wide tensor.
+__global__ __launch_bounds__(256) void thin_conv_fwd8_kernel(const ThinArgs g, const int relu) {
+    const int C = g.C, G = C / 8, cg = threadIdx.x % G, pl = threadIdx.x / G, ppb = 256 / G, o0 = cg * 8;
+    float wk[16][8], b[8];
+#pragma unroll
+    for (int tp = 0; tp < 16; ++tp) {
+        const float4 u = *reinterpret_cast<const float4*>(g.w + tp * C + o0), v = *reinterpret_cast<const float4*>(g.w + tp * C + o0 + 4);
+        wk[tp][0] = u.x; wk[tp][1] = u.y; wk[tp][2] = u.z; wk[tp][3] = u.w; wk[tp][4] = v.x; wk[tp][5] = v.y; wk[tp][6] = v.z; wk[tp][7] = v.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b[e] = g.bias ? g.bias[o0 + e] : 0.f;
+    for (long long p = (long long)blockIdx.x * ppb + pl; p < g.pixels; p += (long long)gridDim.x * ppb) {
+        const int n = (int)(p / (g.Ho * g.Wo)), ij = (int)(p % (g.Ho * g.Wo)), y0 = 2 * (ij / g.Wo) - 1, x0 = 2 * (ij % g.Wo) - 1;
+        const float* img = g.x + (long long)n * g.H * g.W;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = b[e];
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+                const int yy = y0 + kh, xx = x0 + kw;
+                const bool in = yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+                float v = img[(long long)min(max(yy, 0), g.H - 1) * g.W + min(max(xx, 0), g.W - 1)];
+                v = in ? v : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(v, wk[kh * 4 + kw][e], acc[e]);
+            }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaxf(acc[e], 0.f);
+        }
+        if (g.mask) {
+            const float4 u = *reinterpret_cast<const float4*>(g.mask + p * C + o0), v = *reinterpret_cast<const float4*>(g.mask + p * C + o0 + 4);
+            acc[0] = u.x > 0.f ? acc[0] : 0.f; acc[1] = u.y > 0.f ? acc[1] : 0.f; acc[2] = u.z > 0.f ? acc[2] : 0.f; acc[3] = u.w > 0.f ? acc[3] : 0.f;
+            acc[4] = v.x > 0.f ? acc[4] : 0.f; acc[5] = v.y > 0.f ? acc[5] : 0.f; acc[6] = v.z > 0.f ? acc[6] : 0.f; acc[7] = v.w > 0.f ? acc[7] : 0.f;
+        }
+        *reinterpret_cast<float4*>(g.y + p * C + o0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(g.y + p * C + o0 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+// part[block][17][C] as above; the lanes of a wave that share a channel group meet by DPP-free shuffles, the 4 waves through LDS
+__global__ __launch_bounds__(256) void thin_conv_wgrad8_kernel(const ThinArgs g, float* part) {
+    extern __shared__ float red[];                       // [4 waves][17][C]
+    const int C = g.C, G = C / 8, cg = threadIdx.x % G, pl = threadIdx.x / G, ppb = 256 / G, o0 = cg * 8;
+    float acc[17][8];
+#pragma unroll
+    for (int k = 0; k < 17; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[k][e] = 0.f;
+    const long long per = (g.pixels + gridDim.x - 1) / gridDim.x, p0 = blockIdx.x * per, p1 = min(g.pixels, p0 + per);
+    for (long long p = p0 + pl; p < p1; p += ppb) {
+        const int n = (int)(p / (g.Ho * g.Wo)), ij = (int)(p % (g.Ho * g.Wo)), y0 = 2 * (ij / g.Wo) - 1, x0 = 2 * (ij % g.Wo) - 1;
+        const float* img = g.x + (long long)n * g.H * g.W;
+        const float4 u = *reinterpret_cast<const float4*>(g.mask + p * C + o0), v4 = *reinterpret_cast<const float4*>(g.mask + p * C + o0 + 4);
+        const float d[8] = {u.x, u.y, u.z, u.w, v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[16][e] += d[e];
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+                const int yy = y0 + kh, xx = x0 + kw;
+                const bool in = yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+                float v = img[(long long)min(max(yy, 0), g.H - 1) * g.W + min(max(xx, 0), g.W - 1)];
+                v = in ? v : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[kh * 4 + kw][e] = fmaf(v, d[e], acc[kh * 4 + kw][e]);
+            }
+    }
+    // lanes l, l + G, l + 2 G, ... of a wave hold the same channel group (G divides 32): a fixed butterfly over the lane bits above it
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 17; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = acc[k][e];
+            for (int sft = 32; sft >= G; sft >>= 1) v += __shfl_xor(v, sft, 64);
+            acc[k][e] = v;
+        }
+    if (lane < G) {
+#pragma unroll
+        for (int k = 0; k < 17; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[(wave * 17 + k) * C + o0 + e] = acc[k][e];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 17 * C; e += 256)
+        part[(long long)blockIdx.x * 17 * C + e] = (red[e] + red[17 * C + e]) + (red[2 * 17 * C + e] + red[3 * 17 * C + e]);
+}
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static bool thin_channels_ok(int c) { return c >= 1 && c <= 256 && 256 % c == 0; }
+static bool thin_groups_ok(int c) { return c % 8 == 0 && c <= 256 && 256 % c == 0; }     // c / 8 divides 32: lanes of a group stay in a wave
 constexpr int kThinWgradBlocks = 1024;
 
 }  // namespace vaek
@@ -540,6 +633,37 @@ static ConvWFast conv_wgrad_fast(long long batch, int H, int W, int Cin, int Cou
     f.off_x = 256; f.off_dy = f.off_x + up((size_t)batch * H * W * Cin * 2); f.off_slab = f.off_dy + up((size_t)pixels * Cout * 2);
     f.bytes = f.off_slab + (size_t)f.S * (16 * Cin + 1) * Cout * sizeof(float);
     return f;
+}
+
+// The fast form of the forward / transposed forward (C_in a power of two >= 8 / 16, C_out a multiple of 32, a workspace given):
+// bf16 copies of the tensor and the kernel, then gemm_bf16s.hip's LDS-DMA GEMM with the gather in its loader (hs_conv_kernel).
+// Workspace: [256 B zeros | x bf16 | kernel bf16].
+struct ConvFFast { bool ok; size_t off_x, off_w, bytes; };
+static ConvFFast conv_fwd_fast(int mode, long long batch, int H, int W, int Cin, int Cout) {
+    ConvFFast f{};
+    const long long in_px = batch * H * W, M = mode == 0 ? in_px / 4 : in_px;
+    f.ok = (Cin & (Cin - 1)) == 0 && Cin >= (mode == 0 ? 8 : 16) && Cout % 32 == 0 && in_px < 0x7fffffffll && M >= 1 && (M + 127) / 128 * (Cout / 32) < 0x7fffffffll;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    f.off_x = 256; f.off_w = f.off_x + up((size_t)in_px * Cin * 2); f.bytes = f.off_w + up((size_t)16 * Cin * Cout * 2);
+    return f;
+}
+
+extern "C" int vaek_conv2d_forward_workspace(int32_t batch, int32_t height, int32_t width, int32_t c_in, int32_t c_out, int32_t transposed, size_t* bytes) {
+    if (!bytes || batch < 1 || height < 1 || width < 1 || c_in < 1 || c_out < 1) { set_error("vaek_conv2d_forward_workspace: invalid argument"); return VAEK_ERR_INVALID; }
+    const ConvFFast f = conv_fwd_fast(transposed ? 1 : 0, batch, height, width, c_in, c_out);
+    *bytes = f.ok ? f.bytes : 0;
+    return VAEK_OK;
+}
+static int conv_forward_fast(int mode, const ConvFFast& f, const float* x, const float* w, const float* bias, const float* mask, float* out,
+                             void* workspace, int batch, int H, int W, int Cin, int Cout, bool relu, hipStream_t st) {
+    char* ws = static_cast<char*>(workspace);
+    __bf16* zeros = reinterpret_cast<__bf16*>(ws);
+    __bf16* xb = reinterpret_cast<__bf16*>(ws + f.off_x);
+    __bf16* wb = reinterpret_cast<__bf16*>(ws + f.off_w);
+    int rc = launch_cvt_bf16(x, xb, (int64_t)batch * H * W * Cin, zeros, st);
+    if (rc == VAEK_OK) rc = mode == 0 ? launch_cvt_bf16_t(w, wb, 16 * Cin, Cout, st) : launch_cvt_bf16(w, wb, (int64_t)16 * Cin * Cout, nullptr, st);
+    if (rc == VAEK_OK) rc = launch_hs_conv(mode, xb, wb, zeros, bias, mask, out, batch, H, W, Cin, Cout, relu, st);
+    return rc;
 }
 
 extern "C" int vaek_conv2d_weight_grad_workspace(int32_t batch, int32_t height, int32_t width, int32_t c_in, int32_t c_out, size_t* bytes) {
@@ -572,7 +696,8 @@ extern "C" int vaek_conv2d_weight_grad(const float* x, const float* dy, float* d
         const int nb = (int)std::min<long long>(kThinWgradBlocks, (pixels + 255) / 256);
         {
             ProfScope ps("conv_wgrad_thin", st0);
-            launch_k(ps, thin_conv_wgrad_kernel, dim3(nb), dim3(256), 0, st0, ta, part);
+            if (thin_groups_ok(c_out) && aligned16(dy)) launch_k(ps, thin_conv_wgrad8_kernel, dim3(nb), dim3(256), (size_t)4 * 17 * c_out * sizeof(float), st0, ta, part);
+            else launch_k(ps, thin_conv_wgrad_kernel, dim3(nb), dim3(256), 0, st0, ta, part);
             VAEK_HIP_CHECK(hipGetLastError());
         }
         int rc = launch_sum_slabs(part, (int64_t)17 * c_out, nb, dw, (int64_t)16 * c_out, st0);
@@ -624,7 +749,7 @@ extern "C" int vaek_conv2d_bias_grad(const float* dy, float* dbias, void* worksp
 
 extern "C" int vaek_conv2d_transpose_forward(const float* y, const float* w, const float* bias, const float* mask, float* out,
                                              int32_t batch, int32_t height, int32_t width, int32_t c_in, int32_t c_out, int32_t relu,
-                                             void* stream) {
+                                             void* workspace, void* stream) {
     if (!y || !w || !out || batch < 1 || height < 1 || width < 1 || c_in < 1 || c_out < 1) {
         set_error("vaek_conv2d_transpose_forward: invalid argument");
         return VAEK_ERR_INVALID;
@@ -643,6 +768,10 @@ extern "C" int vaek_conv2d_transpose_forward(const float* y, const float* w, con
         VAEK_HIP_CHECK(hipGetLastError());
         return VAEK_OK;
     }
+    if (workspace && aligned16(workspace) && aligned16(y) && aligned16(w) && aligned16(out) && aligned16(mask) && aligned16(bias)) {
+        const ConvFFast f = conv_fwd_fast(1, batch, height, width, c_in, c_out);
+        if (f.ok) return conv_forward_fast(1, f, y, w, bias, mask, out, workspace, batch, height, width, c_in, c_out, relu != 0, (hipStream_t)stream);
+    }
     g.M = (int)M; g.N = c_out; g.K = 4 * c_in; g.relu = relu;
     ProfScope ps("conv_t_fwd_bf16", (hipStream_t)stream);
     launch_k(ps, conv_t_fwd_kernel, dim3((g.N + CBN - 1) / CBN, (g.M + CBM - 1) / CBM, 4), dim3(CNT), 0, (hipStream_t)stream, g);
@@ -651,7 +780,7 @@ extern "C" int vaek_conv2d_transpose_forward(const float* y, const float* w, con
 }
 
 extern "C" int vaek_conv2d_forward(const float* x, const float* w, const float* bias, const float* mask, float* y, int32_t batch,
-                                   int32_t height, int32_t width, int32_t c_in, int32_t c_out, int32_t relu, void* stream) {
+                                   int32_t height, int32_t width, int32_t c_in, int32_t c_out, int32_t relu, void* workspace, void* stream) {
     if (!x || !w || !y || batch < 1 || height < 2 || width < 2 || (height & 1) || (width & 1) || c_in < 1 || c_out < 1) {
         set_error("vaek_conv2d_forward: invalid argument");
         return VAEK_ERR_INVALID;
@@ -666,9 +795,16 @@ extern "C" int vaek_conv2d_forward(const float* x, const float* w, const float* 
         ta.x = x; ta.w = w; ta.bias = bias; ta.mask = mask; ta.y = y;
         ta.B = batch; ta.H = height; ta.W = width; ta.C = c_out; ta.Ho = g.Ho; ta.Wo = g.Wo; ta.pixels = M;
         ProfScope ps("conv_fwd_thin", (hipStream_t)stream);
-        launch_k(ps, thin_conv_fwd_kernel, dim3((unsigned)std::min<long long>(8192, (M * c_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
+        if (thin_groups_ok(c_out) && aligned16(w) && aligned16(y) && aligned16(mask))
+            launch_k(ps, thin_conv_fwd8_kernel, dim3((unsigned)std::min<long long>(8192, (M * (c_out / 8) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
+        else
+            launch_k(ps, thin_conv_fwd_kernel, dim3((unsigned)std::min<long long>(8192, (M * c_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
         VAEK_HIP_CHECK(hipGetLastError());
         return VAEK_OK;
+    }
+    if (workspace && aligned16(workspace) && aligned16(x) && aligned16(w) && aligned16(y) && aligned16(mask) && aligned16(bias)) {
+        const ConvFFast f = conv_fwd_fast(0, batch, height, width, c_in, c_out);
+        if (f.ok) return conv_forward_fast(0, f, x, w, bias, mask, y, workspace, batch, height, width, c_in, c_out, relu != 0, (hipStream_t)stream);
     }
     g.M = (int)M; g.N = c_out; g.K = 16 * c_in; g.relu = relu;
     ProfScope ps("conv_fwd_bf16", (hipStream_t)stream);

@@ -590,6 +590,161 @@ __global__ __launch_bounds__(256) void hs_tn_kernel(const HsDwArgs g) {
     }
 }
 
+// ---- convolution forward / transposed forward on the same loader (conv_bf16.hip) --------------------------------------------------
+// hs_nt_kernel's main loop with the A operand GATHERED: GEMM row m is an output pixel (FWD: of the stride-2 convolution; T: an
+// input-grid pixel of one output parity class, blockIdx.y), k = (tap, channel); every 16-byte chunk (8 channels) is one
+// global_load_lds from the bf16 NHWC image, or from a page of zeros where the tap falls outside it.  B: FWD the [N][K] transposed
+// bf16 copy of the kernel; T the kernel as stored [4][4][C_out][C_in], the class's four [o][c] slices picked per chunk.
+// Epilogue: + bias, relu, relu-mask of the layer below, float32 out (16 bytes per lane and register quad), scattered to the class's
+// pixels for T.  C_in a power of two (>= 8 FWD, >= 16 T), C_out a multiple of BN.
+enum { HC_FWD = 0, HC_T = 1 };
+struct HsConvArgs {
+    const __bf16* X; const __bf16* Wb; const __bf16* zeros;
+    float* out; const float* bias; const float* mask;
+    int relu, H, W, Cin, Cout, M, N, K;       // H, W: the INPUT tensor's spatial size
+    int sh_c, hw, wo;                         // log2 C_in; GEMM rows per image and per image row (FWD: Ho Wo, Wo; T: H W, W)
+};
+template <int MODE, int BN, int WM, int WN, int BK, int NS>
+__global__ __launch_bounds__(64 * WM * WN) void hs_conv_kernel(const HsConvArgs g) {
+    constexpr int BM = 128, NTH = 64 * WM * WN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int RB = 2 * BK, CPR = BK / 8;
+    constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, BUF = A_BYTES + B_BYTES;
+    constexpr int A_PASSES = BM * CPR / NTH, B_PASSES = BN * CPR / NTH, P = A_PASSES + B_PASSES;
+    static_assert(BM * CPR % NTH == 0 && BN * CPR % NTH == 0 && B_PASSES >= 1, "whole staging passes");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned tiles_n = g.N / BN;
+    const int m0 = (int)(blockIdx.x / tiles_n) * BM, n0 = (int)(blockIdx.x % tiles_n) * BN;
+    const int pp = MODE == HC_T ? (int)(blockIdx.y >> 1) : 0, qq = MODE == HC_T ? (int)(blockIdx.y & 1) : 0;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wv / WN, wn = wv % WN;
+    auto swz = [](int row) { return BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; };
+    const int cmask = g.Cin - 1;
+
+    int a_n[A_PASSES], a_y[A_PASSES], a_x[A_PASSES], a_c[A_PASSES];
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+        const int p = i * NTH + t, row = p / CPR;
+        a_c[i] = ((p % CPR) ^ swz(row)) * 8;
+        const int m = min(m0 + row, g.M - 1), n = m / g.hw, ij = m % g.hw, ii = ij / g.wo, jj = ij % g.wo;
+        a_n[i] = n * g.H * g.W;
+        a_y[i] = MODE == HC_FWD ? 2 * ii - 1 : ii + pp;
+        a_x[i] = MODE == HC_FWD ? 2 * jj - 1 : jj + qq;
+    }
+    const __bf16* b_src[B_PASSES]; int b_c[B_PASSES], b_row[B_PASSES];
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+        const int p = i * NTH + t, row = p / CPR;
+        b_c[i] = ((p % CPR) ^ swz(row)) * 8;
+        b_row[i] = min(n0 + row, g.N - 1);
+        b_src[i] = g.Wb + (long long)b_row[i] * g.K + b_c[i];
+    }
+    auto stage = [&](int kt, int slot) {
+        char* base = smem + slot * BUF;
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            const int k = kt * BK + a_c[i], tap = k >> g.sh_c, ch = k & cmask;
+            const int yy = MODE == HC_FWD ? a_y[i] + (tap >> 2) : a_y[i] - (tap >> 1);
+            const int xx = MODE == HC_FWD ? a_x[i] + (tap & 3) : a_x[i] - (tap & 1);
+            const bool in = (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W;
+            const __bf16* src = in ? g.X + (((long long)(a_n[i] + yy * g.W + xx)) << g.sh_c) + ch : g.zeros;
+            glds16(src, base + (i * NTH + wv * 64) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i) {
+            const __bf16* src;
+            if (MODE == HC_FWD) src = b_src[i] + kt * BK;
+            else {
+                const int k = kt * BK + b_c[i], tap = k >> g.sh_c, ch = k & cmask;
+                const int kh = 1 - pp + 2 * (tap >> 1), kw = 1 - qq + 2 * (tap & 1);
+                src = g.Wb + ((long long)((kh * 4 + kw) * g.Cout + b_row[i]) << g.sh_c) + ch;
+            }
+            glds16(src, base + A_BYTES + (i * NTH + wv * 64) * 16);
+        }
+    };
+    const int r = lane & 31, h = lane >> 5;
+    const int arow = wm * (BM / WM) + r, brow = wn * (BN / WN) + r;
+    const int ax = swz(arow), bx = swz(brow);
+    const int a_lo = arow * RB + ((h ^ ax) & 1) * 16, a_x6 = (ax & 6) * 16;
+    const int b_lo = brow * RB + ((h ^ bx) & 1) * 16 + A_BYTES, b_x6 = (bx & 6) * 16;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    const int nt = g.K / BK;
+#pragma unroll
+    for (int q = 0; q < NS - 1; ++q) if (q < nt) stage(q, q);
+    int slot = 0, fill = NS - 1;
+    for (int kt = 0; kt < nt; ++kt) {
+        wait_tiles<P, NS - 2>(min(NS - 2, nt - 1 - kt));
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nt) stage(kt + NS - 1, fill);
+        const char* base = smem + slot * BUF;
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(base + a_lo + i * 32 * RB + ((32 * s) ^ a_x6));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(base + b_lo + j * 32 * RB + ((32 * s) ^ b_x6));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        fill = fill + 1 == NS ? 0 : fill + 1;
+    }
+
+    // ---- epilogue: register 4 q + p of tile (i, j) = C[row][nbase + 32 j + 8 q + 4 h + p]
+    const int nbase = n0 + wn * (BN / WN);
+    const float floor_v = g.relu ? 0.f : -__builtin_huge_valf();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * (BM / WM) + i * 32 + r;
+        if (m >= g.M) continue;
+        long long off;
+        if (MODE == HC_FWD) off = (long long)m * g.N;
+        else {
+            const int n = m / g.hw, ij = m % g.hw, ii = ij / g.wo, jj = ij % g.wo;
+            off = (((long long)n * 2 * g.H + 2 * ii + pp) * 2 * g.W + 2 * jj + qq) * g.N;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = nbase + 32 * j + 8 * q + 4 * h;
+                float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                if (g.bias) {
+                    const float4 b = *reinterpret_cast<const float4*>(g.bias + col);
+                    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                }
+                v.x = fmaxf(v.x, floor_v); v.y = fmaxf(v.y, floor_v); v.z = fmaxf(v.z, floor_v); v.w = fmaxf(v.w, floor_v);
+                if (g.mask) {
+                    const float4 k4 = *reinterpret_cast<const float4*>(g.mask + off + col);
+                    v.x = k4.x > 0.f ? v.x : 0.f; v.y = k4.y > 0.f ? v.y : 0.f; v.z = k4.z > 0.f ? v.z : 0.f; v.w = k4.w > 0.f ? v.w : 0.f;
+                }
+                *reinterpret_cast<float4*>(g.out + off + col) = v;
+            }
+    }
+}
+
+// bf16 [N][K] copy of a float32 [K][N] array (the convolution kernel as the k-contiguous B operand)
+__global__ __launch_bounds__(256) void cvt_bf16_t_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int K, int N) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e < (long long)K * N) {
+        const int n = (int)(e / K), k = (int)(e % K);
+        dst[e] = (__bf16)src[(long long)k * N + n];
+    }
+}
+
 // ---- bf16 copies of the wide layers' kernels ------------------------------------------------------------------------
 struct CvtArgs {
     int n; int K[24], N[24]; long long w_off[24], out_off[24];     // out: W as stored [K, N], then W^T [N, K] (bf16 elements)
@@ -753,6 +908,47 @@ int launch_hs_conv_dw(const __bf16* x, const __bf16* dy, const __bf16* zeros, fl
     if (!attr_set) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
     ProfScope ps("conv_wgrad_bf16s", st);
     launch_k(ps, fn, dim3((unsigned)(g.tiles_m * g.tiles_n * S)), dim3(256), lds, st, g);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+
+// the convolution's forward (mode 0) / transposed forward (mode 1) on bf16 copies; shapes checked by the caller (conv_bf16.hip)
+template <int MODE, int BN, int WM, int WN, int BK, int NS>
+static int hs_conv_launch(const HsConvArgs& g, hipStream_t st) {
+    const auto fn = hs_conv_kernel<MODE, BN, WM, WN, BK, NS>;
+    constexpr size_t lds = (size_t)NS * (128 + BN) * 2 * BK;
+    static thread_local bool attr_set = false;
+    if (!attr_set) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+    ProfScope ps(MODE == HC_FWD ? "conv_fwd_bf16s" : "conv_t_fwd_bf16s", st);
+    launch_k(ps, fn, dim3((unsigned)(((g.M + 127) / 128) * (g.N / BN)), MODE == HC_T ? 4u : 1u), dim3(64 * WM * WN), lds, st, g);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+int launch_hs_conv(int mode, const __bf16* x, const __bf16* wb, const __bf16* zeros, const float* bias, const float* mask, float* out,
+                   int batch, int H, int W, int Cin, int Cout, bool relu, hipStream_t st) {
+    HsConvArgs g{};
+    g.X = x; g.Wb = wb; g.zeros = zeros; g.out = out; g.bias = bias; g.mask = mask; g.relu = relu;
+    g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.N = Cout; g.sh_c = 31 - __builtin_clz(Cin);
+    if (mode == HC_FWD) { g.hw = (H / 2) * (W / 2); g.wo = W / 2; g.K = 16 * Cin; }
+    else { g.hw = H * W; g.wo = W; g.K = 4 * Cin; }
+    const long long M = (long long)batch * g.hw;
+    if ((Cin & (Cin - 1)) || Cout % 32 || g.K % 64 || M > 0x7fffffffll || (long long)batch * H * W > 0x7fffffffll) {
+        set_error("convolution on the bf16-storage loader: unsupported shape");
+        return VAEK_ERR_INVALID;
+    }
+    g.M = (int)M;
+    if (mode == HC_FWD) {
+        if (Cout % 128 == 0) return hs_conv_launch<HC_FWD, 128, 2, 2, 32, 3>(g, st);
+        if (Cout % 64 == 0) return hs_conv_launch<HC_FWD, 64, 2, 2, 32, 4>(g, st);
+        return hs_conv_launch<HC_FWD, 32, 4, 1, 64, 3>(g, st);
+    }
+    if (Cout % 128 == 0) return hs_conv_launch<HC_T, 128, 2, 2, 32, 3>(g, st);
+    if (Cout % 64 == 0) return hs_conv_launch<HC_T, 64, 2, 2, 32, 4>(g, st);
+    return hs_conv_launch<HC_T, 32, 4, 1, 64, 3>(g, st);
+}
+int launch_cvt_bf16_t(const float* src, __bf16* dst, int K, int N, hipStream_t st) {
+    ProfScope ps("cvt_bf16_t", st);
+    launch_k(ps, cvt_bf16_t_kernel, dim3((unsigned)(((long long)K * N + 255) / 256)), dim3(256), 0, st, src, dst, K, N);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
 }
