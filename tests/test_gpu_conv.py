@@ -156,6 +156,17 @@ def test_one_channel_layers_stream_in_exact_float32(B, S, c):
         assert close(conv2d_transpose_forward(_dev(y), _dev(wt), _dev(b1), True, _dev(m2)), np.maximum(want, 0.0) * (m2 > 0))
 
 
+@pytest.mark.parametrize("pixels,c", [(8 * 64 * 64, 1), (8 * 32 * 32, 32), (1001, 4), (37, 2), (50, 12), (9, 1024), (3, 1), (70000, 64)])
+def test_conv2d_bias_grad_sums_the_pixels(pixels, c):
+    from vae_training_amd.conv import conv2d_bias_grad
+    rng = np.random.default_rng(pixels + c)
+    dy = np.asarray(rng.standard_normal((pixels, c)), np.float32)
+    got = conv2d_bias_grad(_dev(dy)).cpu().numpy().astype(np.float64)
+    want = dy.astype(np.float64).sum(axis=0)
+    assert np.max(np.abs(got - want)) <= 1e-5 * np.sqrt(pixels) * max(1.0, np.max(np.abs(want)) / np.sqrt(pixels))
+    assert torch.equal(conv2d_bias_grad(_dev(dy)), conv2d_bias_grad(_dev(dy)))            # fixed-order sums
+
+
 def test_transposed_layer_backward_from_the_same_three_kernels():
     """conv_t_bwd of the oracle (d input, d kernel, d bias of the transposed layer) assembled from the HIP kernels:
     d input = conv2d_forward(d out, K), d kernel = conv2d_weight_grad(x := d out, dy := input) in the [4, 4, C_out, C_in] layout."""

@@ -409,6 +409,40 @@ __global__ __launch_bounds__(256) void conv_colsum_kernel(const float* dy, float
     }
 }
 
+// the same sums as a flat 16-byte stream (C a power of two <= 1024, pixels * C a multiple of 4): thread t of a block always sees the
+// same 4 columns (4 t mod C); four independent accumulators, then the block's threads of one column quad meet through LDS
+__global__ __launch_bounds__(256) void conv_colsum4_kernel(const float4* dy4, float* partial, long long n4, int C, long long chunk) {
+    __shared__ float4 sh[256];
+    const long long f0 = blockIdx.x * chunk, f1 = min(n4, f0 + chunk);
+    float4 a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    long long f = f0 + threadIdx.x;
+    for (; f + 768 < f1; f += 1024) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 v = dy4[f + 256 * u];
+            a[u].x += v.x; a[u].y += v.y; a[u].z += v.z; a[u].w += v.w;
+        }
+    }
+    for (; f < f1; f += 256) {
+        const float4 v = dy4[f];
+        a[0].x += v.x; a[0].y += v.y; a[0].z += v.z; a[0].w += v.w;
+    }
+    sh[threadIdx.x] = make_float4((a[0].x + a[1].x) + (a[2].x + a[3].x), (a[0].y + a[1].y) + (a[2].y + a[3].y),
+                                  (a[0].z + a[1].z) + (a[2].z + a[3].z), (a[0].w + a[1].w) + (a[2].w + a[3].w));
+    __syncthreads();
+    const int Q = C >= 4 ? C / 4 : 1;                    // column quads; Q divides 256
+    if ((int)threadIdx.x < Q) {
+        float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g2 = threadIdx.x; g2 < 256; g2 += Q) { const float4 v = sh[g2]; t4.x += v.x; t4.y += v.y; t4.z += v.z; t4.w += v.w; }
+        float* o = partial + (long long)blockIdx.x * C;
+        if (C >= 4) *reinterpret_cast<float4*>(o + 4 * threadIdx.x) = t4;
+        else if (C == 2) { o[0] = t4.x + t4.z; o[1] = t4.y + t4.w; }
+        else o[0] = (t4.x + t4.y) + (t4.z + t4.w);
+    }
+}
+
 static int conv_wgrad_splits(long long pixels, int M, int N) {
     const long long tiles = (long long)((M + CBM - 1) / CBM) * ((N + CBN - 1) / CBN);
     long long S = std::max(1ll, 1024 / tiles);
@@ -478,6 +512,61 @@ __global__ __launch_bounds__(256) void thin_conv_t_fwd_kernel(const ThinArgs g, 
         if (relu) acc = fmaxf(acc, 0.f);
         if (g.mask) acc = g.mask[p] > 0.f ? acc : 0.f;
         g.y[p] = acc;
+    }
+}
+// The same layer for C a power of two in [4, 256]: C / 4 lanes per INPUT-grid pixel, each with its 4 channels of the 16 kernel taps
+// in registers; the 3 x 3 input neighbourhood (9 coalesced 16-byte loads) feeds the pixel's 2 x 2 output block, the lanes of a
+// pixel meet by a butterfly, lane 0 stores the four values.
+__global__ __launch_bounds__(256) void thin_conv_t_fwd4_kernel(const ThinArgs g, const int relu) {
+    const int C = g.C, LP = C / 4;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x, groups = (long long)gridDim.x * 256 / LP;
+    const int lg = (int)(gid % LP);
+    float4 kk[16];
+#pragma unroll
+    for (int tp = 0; tp < 16; ++tp) kk[tp] = *reinterpret_cast<const float4*>(g.w + tp * C + 4 * lg);
+    const float b = g.bias ? g.bias[0] : 0.f;
+    const long long in_px = (long long)g.B * g.H * g.W, rounds = (in_px + groups - 1) / groups;
+    for (long long it = 0; it < rounds; ++it) {           // every lane runs every round: the butterfly needs the whole group
+        const long long p = gid / LP + it * groups;
+        const bool live = p < in_px;
+        const long long pc = live ? p : in_px - 1;
+        const int n = (int)(pc / (g.H * g.W)), ij = (int)(pc % (g.H * g.W)), i = ij / g.W, j = ij % g.W;
+        float4 v[3][3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int yy = i - 1 + dy, xx = j - 1 + dx;
+                const bool in = yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+                const float4 f = *reinterpret_cast<const float4*>(g.x + (((long long)n * g.H + min(max(yy, 0), g.H - 1)) * g.W + min(max(xx, 0), g.W - 1)) * C + 4 * lg);
+                v[dy][dx] = in ? f : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        float o[2][2];
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                float acc = 0.f;
+#pragma unroll
+                for (int th = 0; th < 2; ++th)
+#pragma unroll
+                    for (int tw = 0; tw < 2; ++tw) {      // input pixel (i + pp - th, j + qq - tw) = v[1 + pp - th][1 + qq - tw]
+                        const float4 f = v[1 + pp - th][1 + qq - tw], k4 = kk[(1 - pp + 2 * th) * 4 + (1 - qq + 2 * tw)];
+                        acc = fmaf(f.x, k4.x, acc); acc = fmaf(f.y, k4.y, acc); acc = fmaf(f.z, k4.z, acc); acc = fmaf(f.w, k4.w, acc);
+                    }
+                for (int sft = LP >> 1; sft >= 1; sft >>= 1) acc += __shfl_xor(acc, sft, 64);
+                o[pp][qq] = acc + b;
+            }
+        if (live && lg == 0) {
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const long long off = ((long long)n * 2 * g.H + 2 * i + pp) * 2 * g.W + 2 * j;
+                float2 r2 = make_float2(o[pp][0], o[pp][1]);
+                if (relu) { r2.x = fmaxf(r2.x, 0.f); r2.y = fmaxf(r2.y, 0.f); }
+                if (g.mask) { const float2 m2 = *reinterpret_cast<const float2*>(g.mask + off); r2.x = m2.x > 0.f ? r2.x : 0.f; r2.y = m2.y > 0.f ? r2.y : 0.f; }
+                *reinterpret_cast<float2*>(g.y + off) = r2;
+            }
+        }
     }
 }
 // kernel gradient with a one-channel gathered tensor: part[block][tap or 16 = bias][o] = sum over the block's pixels of
@@ -739,6 +828,18 @@ extern "C" int vaek_conv2d_bias_grad(const float* dy, float* dbias, void* worksp
     const int S = (int)std::min<long long>(512, (pixels + 255) / 256);
     const long long rps = (pixels + S - 1) / S;
     hipStream_t st = (hipStream_t)stream;
+    const long long n = pixels * c;
+    if ((c & (c - 1)) == 0 && c <= 1024 && n % 4 == 0 && aligned16(dy) && aligned16(workspace)) {
+        const long long n4 = n / 4;
+        const int S4 = (int)std::min<long long>(512, (n4 + 1023) / 1024);
+        const long long chunk = ((n4 + S4 - 1) / S4 + 255) / 256 * 256;          // a multiple of 256 float4s: the column phase of a thread is fixed
+        {
+            ProfScope ps("conv_bias_grad", st);
+            launch_k(ps, conv_colsum4_kernel, dim3(S4), dim3(256), 0, st, reinterpret_cast<const float4*>(dy), static_cast<float*>(workspace), n4, (int)c, chunk);
+            VAEK_HIP_CHECK(hipGetLastError());
+        }
+        return launch_sum_slabs(static_cast<const float*>(workspace), c, S4, dbias, c, st);
+    }
     {
         ProfScope ps("conv_bias_grad", st);
         launch_k(ps, conv_colsum_kernel, dim3(S), dim3(256), 256 * sizeof(float), st, dy, static_cast<float*>(workspace), (long long)pixels, (int)c, rps);
@@ -764,7 +865,10 @@ extern "C" int vaek_conv2d_transpose_forward(const float* y, const float* w, con
         ta.x = y; ta.w = w; ta.bias = bias; ta.mask = mask; ta.y = out;
         ta.B = batch; ta.H = height; ta.W = width; ta.C = c_in; ta.pixels = 4 * M;
         ProfScope ps("conv_t_fwd_thin", (hipStream_t)stream);
-        launch_k(ps, thin_conv_t_fwd_kernel, dim3((unsigned)std::min<long long>(16384, (4 * M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
+        if ((c_in & (c_in - 1)) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0 && (reinterpret_cast<uintptr_t>(mask) & 7) == 0)
+            launch_k(ps, thin_conv_t_fwd4_kernel, dim3((unsigned)std::min<long long>(8192, (M * (c_in / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
+        else
+            launch_k(ps, thin_conv_t_fwd_kernel, dim3((unsigned)std::min<long long>(16384, (4 * M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
         VAEK_HIP_CHECK(hipGetLastError());
         return VAEK_OK;
     }
