@@ -239,29 +239,36 @@ int vaek_train_steps_status(vaek_ctx* ctx, void* workspace, int32_t* gave_up);
  * 4 x 4 / stride 2 / pad 1 convolution, NHWC float32 tensors, HWIO kernel [4][4][c_in][c_out], bf16 matrix-core products with
  * float32 accumulation (the envelope of the bf16 Dense path, not the 1e-5 ELBO contract):
  *   y[n, i, j, o] = act(bias[o] + sum_{kh, kw, c} x[n, 2 i + kh - 1, 2 j + kw - 1, c] * w[kh, kw, c, o]),  y: [batch, height/2, width/2, c_out].
- * No context needed.  With the two entry points below every product of both layer kinds' forward and backward passes exists; the
- * convolutional VAE's train step is not assembled yet. */
-/* `workspace`: vaek_conv2d_forward_workspace bytes (transposed = 0 / 1 for the two entry points; 0 bytes = none needed), 16-byte
+ * No context needed.  With the entry points below every product of both layer kinds' forward and backward passes exists
+ * (vae_training_amd/conv_vae.py assembles the train step from them).
+ * `workspace`: vaek_conv2d_forward_workspace bytes (transposed = 0 / 1 for the two entry points; 0 bytes = none needed), 16-byte
  * aligned, or NULL.  With a workspace, c_in a power of two (>= 8; >= 16 transposed), c_out a multiple of 32 and 16-byte aligned
  * tensors the layer runs on bf16 copies through the LDS-DMA GEMM (the same bf16 products, several times faster); otherwise, and
  * always for NULL, the register-staged kernel.  Layers with ONE channel on the thin side (c_in = 1 here, c_out = 1 transposed)
- * are streaming float32 kernels -- exact, no bf16 rounding. */
+ * are streaming float32 kernels -- exact, no bf16 rounding.
+ * bf16 copies (all optional, NULL = none; 16-byte aligned): `x_bf16` / `dy_bf16` / `y_bf16` INPUTS are bf16 images of the float32
+ * tensor of the same name that the caller vouches for (an earlier call's output copy, or vaek_to_bf16) -- the LDS-DMA form then
+ * skips its own conversion pass, the other forms ignore them; `y_bf16` / `out_bf16` OUTPUTS are written with the bf16 rounding of
+ * the float32 result in every form (from the epilogue where the form can, by a conversion pass otherwise). */
 int vaek_conv2d_forward_workspace(int32_t batch, int32_t height, int32_t width, int32_t c_in, int32_t c_out, int32_t transposed, size_t* bytes);
 int vaek_conv2d_forward(const float* x, const float* w, const float* bias, const float* mask, float* y, int32_t batch, int32_t height,
-                        int32_t width, int32_t c_in, int32_t c_out, int32_t relu, void* workspace, void* stream);   /* mask: as below; NULL = none */
+                        int32_t width, int32_t c_in, int32_t c_out, int32_t relu, void* workspace, const void* x_bf16, void* y_bf16,
+                        void* stream);   /* mask: as below; NULL = none */
+int vaek_to_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);      /* n floats -> n bf16, round to nearest even */
 /* The transposed convolution of the same specification = the adjoint of vaek_conv2d_forward with the SAME kernel array
  * (oracle: conv_t_fwd): y [batch, height, width, c_in], w [4][4][c_out][c_in] (the HWIO kernel of the convolution it is the adjoint
  * of), out [batch, 2 height, 2 width, c_out] = act(bias + ...).  It is also the convolution's input gradient (y := dL/d output, bias
  * NULL); `mask` (NULL or a tensor of out's shape) multiplies the result by [mask > 0] -- the relu of the layer below. */
 int vaek_conv2d_transpose_forward(const float* y, const float* w, const float* bias, const float* mask, float* out, int32_t batch,
-                                  int32_t height, int32_t width, int32_t c_in, int32_t c_out, int32_t relu, void* workspace, void* stream);
+                                  int32_t height, int32_t width, int32_t c_in, int32_t c_out, int32_t relu, void* workspace,
+                                  const void* y_bf16, void* out_bf16, void* stream);
 /* Kernel gradient of vaek_conv2d_forward (oracle: conv_bwd): dw[kh, kw, c, o] = sum_{n, i, j} x[n, 2 i + kh - 1, 2 j + kw - 1, c] *
  * dy[n, i, j, o], dbias[o] = sum dy (NULL: not wanted); x [batch, height, width, c_in], dy [batch, height/2, width/2, c_out].
  * Batch-split slabs in `workspace` (vaek_conv2d_weight_grad_workspace bytes) + a fixed-order sum: bitwise repeatable.  With
  * (x := dL/d out, dy := the layer's input) it is the TRANSPOSED layer's kernel gradient in its [4][4][c_out][c_in] layout. */
 int vaek_conv2d_weight_grad_workspace(int32_t batch, int32_t height, int32_t width, int32_t c_in, int32_t c_out, size_t* bytes);
 int vaek_conv2d_weight_grad(const float* x, const float* dy, float* dw, float* dbias, void* workspace, int32_t batch, int32_t height,
-                            int32_t width, int32_t c_in, int32_t c_out, void* stream);
+                            int32_t width, int32_t c_in, int32_t c_out, const void* x_bf16, const void* dy_bf16, void* stream);
 /* dbias[c] = sum over the pixels of dy[pixels][c] (the bias gradient of a transposed layer); workspace: 512 * c floats. */
 int vaek_conv2d_bias_grad(const float* dy, float* dbias, void* workspace, int64_t pixels, int32_t c, void* stream);
 /* Dense + reparameterisation (networks.py:72-74) as one block: mu = x @ w + b, samples = mu + exp(logvar_e / 2) * z1. */

@@ -58,6 +58,26 @@ def test_lds_dma_and_register_staged_forms_agree():
     assert float((a - c).abs().max()) <= 1e-5 * float(c.abs().max())
 
 
+def test_bf16_copies_in_and_out_change_nothing():
+    """x16 / want16 (conv.py): with the operand copy handed in the result is bitwise the same; the copy handed out is the bf16
+    rounding of the float32 result in every form (epilogue or conversion pass)."""
+    from vae_training_amd.conv import conv2d_forward, conv2d_transpose_forward, conv2d_weight_grad, to_bf16
+    torch.manual_seed(2)
+    for cin, cout in ((32, 64), (1, 32), (12, 16)):                     # LDS-DMA form, streaming form, register-staged form
+        x = torch.randn(5, 16, 16, cin, device="cuda"); K = torch.randn(4, 4, cin, cout, device="cuda") / 8; dy = torch.randn(5, 8, 8, cout, device="cuda")
+        x16 = to_bf16(x)
+        assert torch.equal(x16, x.to(torch.bfloat16))
+        y0 = conv2d_forward(x, K, None, True)
+        y1, y16 = conv2d_forward(x, K, None, True, x16=x16, want16=True)
+        assert torch.equal(y0, y1) and torch.equal(y16, y1.to(torch.bfloat16))
+        a, _ = conv2d_weight_grad(x, dy)
+        b, _ = conv2d_weight_grad(x, dy, x16=x16, dy16=to_bf16(dy))
+        assert torch.equal(a, b)
+        t0 = conv2d_transpose_forward(dy, K)
+        t1, t16 = conv2d_transpose_forward(dy, K, y16=to_bf16(dy), want16=True)
+        assert torch.equal(t0, t1) and torch.equal(t16, t1.to(torch.bfloat16))
+
+
 def test_conv2d_forward_rejects_odd_sizes():
     from vae_training_amd._lib import VaekError
     from vae_training_amd.conv import conv2d_forward
@@ -276,27 +296,35 @@ def _checked_conv_calls(monkeypatch, log):
         ref = torch.relu(ref) if relu else ref
         return ref if mask is None else ref * (mask.cpu() > 0)
 
-    def fwd(x, w, bias=None, relu=False, mask=None, out=None):
-        y = o_f(x, w, bias, relu, mask, out)
+    def same16(t, t16):              # a bf16 copy handed along must BE the bf16 rounding of the float32 tensor
+        return t16 is None or torch.equal(t16, t.to(torch.bfloat16))
+
+    def fwd(x, w, bias=None, relu=False, mask=None, out=None, **kw):
+        res = o_f(x, w, bias, relu, mask, out, **kw)
+        y, y16 = res if isinstance(res, tuple) else (res, None)
         r = ident if x.shape[3] == 1 and 256 % w.shape[3] == 0 else rb
         ref = F.conv2d(r(nchw(x)), r(oihw(w)), None if bias is None else bias.double().cpu(), stride=2, padding=1)
         log.append(("forward", tuple(x.shape), rel(y, finish(ref, relu, mask))))
-        return y
+        assert same16(x, kw.get("x16")) and same16(y, y16) and (y16 is not None) == bool(kw.get("want16"))
+        return res
 
-    def tfwd(y, w, bias=None, relu=False, mask=None):
-        out = o_t(y, w, bias, relu, mask)
+    def tfwd(y, w, bias=None, relu=False, mask=None, **kw):
+        res = o_t(y, w, bias, relu, mask, **kw)
+        out, out16 = res if isinstance(res, tuple) else (res, None)
         r = ident if w.shape[2] == 1 and w.shape[3] % 4 == 0 and w.shape[3] <= 256 else rb
         ref = F.conv_transpose2d(r(nchw(y)), r(oihw(w)), None if bias is None else bias.double().cpu(), stride=2, padding=1)
         log.append(("transposed", tuple(y.shape), rel(out, finish(ref, relu, mask))))
-        return out
+        assert same16(y, kw.get("y16")) and same16(out, out16) and (out16 is not None) == bool(kw.get("want16"))
+        return res
 
-    def wgrad(x, dy, want_bias=True, dw=None, db=None):
-        dw, db = o_w(x, dy, want_bias, dw, db)
+    def wgrad(x, dy, want_bias=True, dw=None, db=None, **kw):
+        dw, db = o_w(x, dy, want_bias, dw, db, **kw)
         r = ident if x.shape[3] == 1 and 256 % dy.shape[3] == 0 else rb
         ref = torch.nn.grad.conv2d_weight(r(nchw(x)), (dy.shape[3], x.shape[3], 4, 4), r(nchw(dy)), stride=2, padding=1).permute(2, 3, 1, 0)
         log.append(("kernel gradient", tuple(x.shape), rel(dw.reshape(ref.shape), ref)))
         if db is not None:
             log.append(("bias gradient", tuple(x.shape), rel(db, r(dy.double().cpu()).sum(dim=(0, 1, 2)))))      # a ones row of the same bf16 product
+        assert same16(x, kw.get("x16")) and same16(dy, kw.get("dy16"))
         return dw, db
 
     monkeypatch.setattr(CV, "conv2d_forward", fwd)

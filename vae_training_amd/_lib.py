@@ -70,14 +70,15 @@ SIGNATURES = {
     "vaek_supports_train_steps": (C.c_int, [_vp, C.POINTER(_i32)]),
     "vaek_train_steps": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp]),
     "vaek_train_steps_status": (C.c_int, [_vp, _vp, C.POINTER(_i32)]),
-    "vaek_conv2d_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "vaek_conv2d_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "vaek_to_bf16": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "vaek_conv2d_forward_workspace": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_size_t)]),
     "vaek_conv2d_bias_grad": (C.c_int, [_vp, _vp, _vp, C.c_int64, _i32, _vp]),
     "vaek_dense_fwd_reparam": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vaek_reparam_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_int64, _vp, _vp]),
-    "vaek_conv2d_transpose_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "vaek_conv2d_transpose_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "vaek_conv2d_weight_grad_workspace": (C.c_int, [_i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_size_t)]),
-    "vaek_conv2d_weight_grad": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vaek_conv2d_weight_grad": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "vaek_rng_fill": (C.c_int, [_vp, _vp, _vp, _i64, C.c_uint64, C.c_uint32, C.c_uint32, _vp]),
     "vaek_set_loss_history": (C.c_int, [_vp, _vp, _i64]),
     "vaek_microbench_copy": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),

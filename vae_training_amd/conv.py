@@ -15,49 +15,70 @@ def _forward_workspace(lib, B, H, W, Cin, Cout, transposed, device, fast):
     return torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=device) if nbytes.value else None
 
 
-def conv2d_forward(x, w, bias=None, relu=False, mask=None, out=None, fast=True):
+def _bf16_like(t):
+    return torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+
+
+def to_bf16(t):
+    """bf16 copy of a contiguous float32 device tensor (vaek_to_bf16) -- the operand copy the LDS-DMA kernels read."""
+    lib = _lib.load()
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    out = _bf16_like(t)
+    _lib.check(lib.vaek_to_bf16(C.c_void_p(t.data_ptr()), C.c_void_p(out.data_ptr()), t.numel(),
+                                C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return out
+
+
+def conv2d_forward(x, w, bias=None, relu=False, mask=None, out=None, fast=True, x16=None, want16=False):
     """4 x 4 / stride 2 / pad 1 convolution: x [B, H, W, Cin] float32 NHWC, w [4, 4, Cin, Cout] HWIO -> [B, H/2, W/2, Cout]
-    (vaek_conv2d_forward: implicit GEMM on the bf16 matrix cores, float32 accumulation)."""
+    (vaek_conv2d_forward: implicit GEMM on the bf16 matrix cores, float32 accumulation; a streaming f32 kernel for Cin = 1).
+    x16: a bf16 copy of x from an earlier call (skips the conversion pass); want16: also return the bf16 copy of the result."""
     lib = _lib.load()
     assert x.is_cuda and w.is_cuda and x.dtype == w.dtype == torch.float32 and x.is_contiguous() and w.is_contiguous()
     B, H, W, Cin = x.shape
     assert tuple(w.shape[:3]) == (4, 4, Cin)
+    assert x16 is None or (x16.dtype == torch.bfloat16 and x16.shape == x.shape and x16.is_contiguous())
     Cout = w.shape[3]
     y = torch.empty(B, H // 2, W // 2, Cout, dtype=torch.float32, device=x.device) if out is None else out
+    y16 = _bf16_like(y) if want16 else None
     assert mask is None or (mask.shape == y.shape and mask.is_contiguous())
     p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
     ws = _forward_workspace(lib, B, H, W, Cin, Cout, False, x.device, fast)      # fast=False: the register-staged kernel
-    _lib.check(lib.vaek_conv2d_forward(p(x), p(w), p(bias), p(mask), p(y), B, H, W, Cin, Cout, int(bool(relu)), p(ws),
+    _lib.check(lib.vaek_conv2d_forward(p(x), p(w), p(bias), p(mask), p(y), B, H, W, Cin, Cout, int(bool(relu)), p(ws), p(x16), p(y16),
                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-    return y
+    return (y, y16) if want16 else y
 
 
-def conv2d_transpose_forward(y, w, bias=None, relu=False, mask=None, fast=True):
+def conv2d_transpose_forward(y, w, bias=None, relu=False, mask=None, fast=True, y16=None, want16=False):
     """The adjoint of conv2d_forward with the same kernel array: y [B, h, w, Cin], w [4, 4, Cout, Cin] -> [B, 2 h, 2 w, Cout]
     (vaek_conv2d_transpose_forward).  With bias=None it is the convolution's input gradient; `mask` applies the relu of the layer
-    below ([mask > 0])."""
+    below ([mask > 0]).  y16 / want16: as in conv2d_forward."""
     lib = _lib.load()
     assert y.is_cuda and w.is_cuda and y.dtype == w.dtype == torch.float32 and y.is_contiguous() and w.is_contiguous()
     B, h, wd, Cin = y.shape
     assert tuple(w.shape[:2]) == (4, 4) and w.shape[3] == Cin
+    assert y16 is None or (y16.dtype == torch.bfloat16 and y16.shape == y.shape and y16.is_contiguous())
     Cout = w.shape[2]
     out = torch.empty(B, 2 * h, 2 * wd, Cout, dtype=torch.float32, device=y.device)
+    out16 = _bf16_like(out) if want16 else None
     assert mask is None or (mask.shape == out.shape and mask.is_contiguous())
     p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
     ws = _forward_workspace(lib, B, h, wd, Cin, Cout, True, y.device, fast)
-    _lib.check(lib.vaek_conv2d_transpose_forward(p(y), p(w), p(bias), p(mask), p(out), B, h, wd, Cin, Cout, int(bool(relu)), p(ws),
-                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-    return out
+    _lib.check(lib.vaek_conv2d_transpose_forward(p(y), p(w), p(bias), p(mask), p(out), B, h, wd, Cin, Cout, int(bool(relu)), p(ws), p(y16),
+                                                 p(out16), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return (out, out16) if want16 else out
 
 
-def conv2d_weight_grad(x, dy, want_bias=True, dw=None, db=None):
+def conv2d_weight_grad(x, dy, want_bias=True, dw=None, db=None, x16=None, dy16=None):
     """Kernel (and bias) gradient of conv2d_forward: x [B, H, W, Cin], dy [B, H/2, W/2, Cout] -> (dw [4, 4, Cin, Cout], db [Cout] or None)
-    (vaek_conv2d_weight_grad: batch-split implicit GEMM + fixed-order slab sum)."""
+    (vaek_conv2d_weight_grad: batch-split implicit GEMM + fixed-order slab sum).  x16 / dy16: bf16 copies from earlier calls."""
     lib = _lib.load()
     assert x.is_cuda and dy.is_cuda and x.dtype == dy.dtype == torch.float32 and x.is_contiguous() and dy.is_contiguous()
     B, H, W, Cin = x.shape
     Cout = dy.shape[3]
     assert tuple(dy.shape[:3]) == (B, H // 2, W // 2)
+    assert x16 is None or (x16.dtype == torch.bfloat16 and x16.shape == x.shape and x16.is_contiguous())
+    assert dy16 is None or (dy16.dtype == torch.bfloat16 and dy16.shape == dy.shape and dy16.is_contiguous())
     nbytes = C.c_size_t()
     _lib.check(lib.vaek_conv2d_weight_grad_workspace(B, H, W, Cin, Cout, C.byref(nbytes)))
     ws = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=x.device)
@@ -66,7 +87,7 @@ def conv2d_weight_grad(x, dy, want_bias=True, dw=None, db=None):
         db = torch.empty(Cout, dtype=torch.float32, device=x.device)
     assert dw.is_contiguous() and dw.numel() == 16 * Cin * Cout
     p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
-    _lib.check(lib.vaek_conv2d_weight_grad(p(x), p(dy), p(dw), p(db), p(ws), B, H, W, Cin, Cout,
+    _lib.check(lib.vaek_conv2d_weight_grad(p(x), p(dy), p(dw), p(db), p(ws), B, H, W, Cin, Cout, p(x16), p(dy16),
                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     return dw, db
 

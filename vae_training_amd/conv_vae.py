@@ -13,15 +13,21 @@ A train step is assembled here from the library's blocks (include/vaek.h), every
   update    vaek_adam_step over the flat parameter vector
 Parameters, gradients and Adam moments are ONE flat float32 buffer each, in the leaf order of ConvVAE.leaves() (the oracle's);
 PyTorch holds the device memory and slices views -- it computes nothing.  This is a first, launch-per-layer assembly (about 40
-launches per step, and one host read of the epsilon parameter per step): correct first, not fast yet."""
+launches per step, and one host read of the epsilon parameter per step).  Tensors that a bf16-operand kernel reads again travel
+with a bf16 copy written by the epilogue that produced them (conv.py: x16 / want16), so nothing is converted twice."""
 import math
 
 import torch
 
-from .conv import conv2d_bias_grad, conv2d_forward, conv2d_transpose_forward, conv2d_weight_grad
+from .conv import conv2d_bias_grad, conv2d_forward, conv2d_transpose_forward, conv2d_weight_grad, to_bf16
 from .engine import Engine
 
 KS = 4
+
+
+def _pair(r):
+    """(tensor, bf16 copy or None) from a conv wrapper's result."""
+    return r if isinstance(r, tuple) else (r, None)
 
 
 class ConvVAE:
@@ -71,25 +77,29 @@ class ConvVAE:
         B, S, L, e = x.shape[0], self.S, self.L, self.eng
         P = lambda n: self.view(params, n)
         G = lambda n: self.view(grads, n)
-        # ---- forward
-        acts = [x]
+        # ---- forward (every tensor a bf16-operand kernel will read again gets its bf16 copy from the epilogue that produces it)
+        acts, acts16 = [x], [None]
         for i in range(4):
-            acts.append(conv2d_forward(acts[-1], P(f"Encoder/Conv{i}/kernel"), P(f"Encoder/Conv{i}/bias"), relu=True))
+            y, y16 = _pair(conv2d_forward(acts[-1], P(f"Encoder/Conv{i}/kernel"), P(f"Encoder/Conv{i}/bias"), relu=True, x16=acts16[-1], want16=i < 3))
+            acts.append(y); acts16.append(y16)
         flat = acts[-1].view(B, self.bott)
         lv = P("epsilon_p")
         mu, samples = e.dense_fwd_reparam(flat, P("Encoder/FC/kernel"), P("Encoder/FC/bias"), z1, lv)
         dec = [e.dense_fwd(samples, P("Decoder/FC/kernel"), P("Decoder/FC/bias"), relu=True).view(B, S // 16, S // 16, self.widths[3])]
+        dec16 = [to_bf16(dec[0])]
         for i in range(4):
-            dec.append(conv2d_transpose_forward(dec[-1], P(f"Decoder/ConvT{i}/kernel"), P(f"Decoder/ConvT{i}/bias"), relu=i < 3))
+            y, y16 = _pair(conv2d_transpose_forward(dec[-1], P(f"Decoder/ConvT{i}/kernel"), P(f"Decoder/ConvT{i}/bias"), relu=i < 3,
+                                                    y16=dec16[-1], want16=i < 2))
+            dec.append(y); dec16.append(y16)
         eps = float(P("epsilon")[0]) * self.eps_cli if self.tdv else self.eps_cli        # one host read per step (see the module text)
         out4, d, _ = e.elbo_fwd_bwd(x.view(B, S * S), dec[4].view(B, S * S), None, z2.view(B, S * S), mu, lv, eps)
         # ---- backward: decoder
-        d = d.view(B, S, S, 1)
+        d, d16 = d.view(B, S, S, 1), None
         for i in reversed(range(4)):
             inp = dec[i]
-            conv2d_weight_grad(d, inp, want_bias=False, dw=G(f"Decoder/ConvT{i}/kernel"))
+            conv2d_weight_grad(d, inp, want_bias=False, dw=G(f"Decoder/ConvT{i}/kernel"), x16=d16, dy16=dec16[i])
             conv2d_bias_grad(d, G(f"Decoder/ConvT{i}/bias"))
-            d = conv2d_forward(d, P(f"Decoder/ConvT{i}/kernel"), None, relu=False, mask=inp)      # adjoint of the adjoint + relu below
+            d, d16 = _pair(conv2d_forward(d, P(f"Decoder/ConvT{i}/kernel"), None, relu=False, mask=inp, x16=d16, want16=i > 0))   # adjoint of the adjoint + relu below
         d = d.view(B, self.bott)
         dwb = e.dense_bwd_dw(samples, d)                                                          # [kernel | bias] rows
         G("Decoder/FC/kernel").copy_(dwb[:L]); G("Decoder/FC/bias").copy_(dwb[L])
@@ -98,12 +108,13 @@ class ConvVAE:
         dwb = e.dense_bwd_dw(flat, d_s)
         G("Encoder/FC/kernel").copy_(dwb[:self.bott]); G("Encoder/FC/bias").copy_(dwb[self.bott])
         d = e.dense_bwd_dx(d_s, P("Encoder/FC/kernel"), flat, relu=True).view(B, S // 16, S // 16, self.widths[3])
+        d16 = to_bf16(d)
         # ---- backward: encoder
         for i in reversed(range(4)):
             inp = acts[i]
-            conv2d_weight_grad(inp, d, dw=G(f"Encoder/Conv{i}/kernel"), db=G(f"Encoder/Conv{i}/bias"))
+            conv2d_weight_grad(inp, d, dw=G(f"Encoder/Conv{i}/kernel"), db=G(f"Encoder/Conv{i}/bias"), x16=acts16[i], dy16=d16)
             if i > 0:
-                d = conv2d_transpose_forward(d, P(f"Encoder/Conv{i}/kernel"), None, relu=False, mask=inp)
+                d, d16 = _pair(conv2d_transpose_forward(d, P(f"Encoder/Conv{i}/kernel"), None, relu=False, mask=inp, y16=d16, want16=i > 1))
         if self.tdv:
             G("epsilon").copy_(out4[3:4] * self.eps_cli)                                          # eps = param * eps_cli
         return out4

@@ -453,7 +453,7 @@ static int conv_wgrad_splits(long long pixels, int M, int N) {
 // ---- the one-channel layers (the first convolution, the last transposed convolution and their gradients): streaming kernels --------
 // 16 or 128 multiply-adds per output value against 4 to 128 bytes of traffic: HBM-bound, nothing for the matrix cores.  Exact f32.
 struct ThinArgs {
-    const float* x; const float* w; const float* bias; const float* mask; float* y;
+    const float* x; const float* w; const float* bias; const float* mask; float* y; __bf16* y16;
     int B, H, W, C, Ho, Wo; long long pixels;          // C: the wide side's channel count
 };
 // forward, C_in = 1: y[p, o] = act(b[o] + sum_taps x_window[p, tap] K[tap, o]).  Thread = (pixel lane, o); C | 256.
@@ -643,6 +643,11 @@ __global__ __launch_bounds__(256) void thin_conv_fwd8_kernel(const ThinArgs g, c
         }
         *reinterpret_cast<float4*>(g.y + p * C + o0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         *reinterpret_cast<float4*>(g.y + p * C + o0 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        if (g.y16) {
+            typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+            const bf16x8_t o8 = {(__bf16)acc[0], (__bf16)acc[1], (__bf16)acc[2], (__bf16)acc[3], (__bf16)acc[4], (__bf16)acc[5], (__bf16)acc[6], (__bf16)acc[7]};
+            *reinterpret_cast<bf16x8_t*>(g.y16 + p * C + o0) = o8;
+        }
     }
 }
 // part[block][17][C] as above; the lanes of a wave that share a channel group meet by DPP-free shuffles, the 4 waves through LDS
@@ -744,14 +749,19 @@ extern "C" int vaek_conv2d_forward_workspace(int32_t batch, int32_t height, int3
     return VAEK_OK;
 }
 static int conv_forward_fast(int mode, const ConvFFast& f, const float* x, const float* w, const float* bias, const float* mask, float* out,
-                             void* workspace, int batch, int H, int W, int Cin, int Cout, bool relu, hipStream_t st) {
+                             void* workspace, const void* x16, void* out16, int batch, int H, int W, int Cin, int Cout, bool relu, hipStream_t st) {
     char* ws = static_cast<char*>(workspace);
     __bf16* zeros = reinterpret_cast<__bf16*>(ws);
-    __bf16* xb = reinterpret_cast<__bf16*>(ws + f.off_x);
+    const __bf16* xb = static_cast<const __bf16*>(x16);
     __bf16* wb = reinterpret_cast<__bf16*>(ws + f.off_w);
-    int rc = launch_cvt_bf16(x, xb, (int64_t)batch * H * W * Cin, zeros, st);
-    if (rc == VAEK_OK) rc = mode == 0 ? launch_cvt_bf16_t(w, wb, 16 * Cin, Cout, st) : launch_cvt_bf16(w, wb, (int64_t)16 * Cin * Cout, nullptr, st);
-    if (rc == VAEK_OK) rc = launch_hs_conv(mode, xb, wb, zeros, bias, mask, out, batch, H, W, Cin, Cout, relu, st);
+    int rc = VAEK_OK;
+    if (!xb) {                                            // no copy handed in: make one
+        __bf16* mine = reinterpret_cast<__bf16*>(ws + f.off_x);
+        rc = launch_cvt_bf16(x, mine, (int64_t)batch * H * W * Cin, nullptr, st);
+        xb = mine;
+    }
+    if (rc == VAEK_OK) rc = mode == 0 ? launch_cvt_bf16_t(w, wb, 16 * Cin, Cout, zeros, st) : launch_cvt_bf16(w, wb, (int64_t)16 * Cin * Cout, zeros, st);
+    if (rc == VAEK_OK) rc = launch_hs_conv(mode, xb, wb, zeros, bias, mask, out, static_cast<__bf16*>(out16), batch, H, W, Cin, Cout, relu, st);
     return rc;
 }
 
@@ -766,8 +776,10 @@ extern "C" int vaek_conv2d_weight_grad_workspace(int32_t batch, int32_t height, 
 }
 
 extern "C" int vaek_conv2d_weight_grad(const float* x, const float* dy, float* dw, float* dbias, void* workspace, int32_t batch,
-                                       int32_t height, int32_t width, int32_t c_in, int32_t c_out, void* stream) {
-    if (!x || !dy || !dw || !workspace || batch < 1 || height < 2 || width < 2 || (height & 1) || (width & 1) || c_in < 1 || c_out < 1) {
+                                       int32_t height, int32_t width, int32_t c_in, int32_t c_out, const void* x_bf16, const void* dy_bf16,
+                                       void* stream) {
+    if (!x || !dy || !dw || !workspace || batch < 1 || height < 2 || width < 2 || (height & 1) || (width & 1) || c_in < 1 || c_out < 1 ||
+        !aligned16(x_bf16) || !aligned16(dy_bf16)) {
         set_error("vaek_conv2d_weight_grad: invalid argument");
         return VAEK_ERR_INVALID;
     }
@@ -797,12 +809,22 @@ extern "C" int vaek_conv2d_weight_grad(const float* x, const float* dy, float* d
     if (f.ok) {
         char* ws = static_cast<char*>(workspace);
         __bf16* zeros = reinterpret_cast<__bf16*>(ws);
-        __bf16* xb = reinterpret_cast<__bf16*>(ws + f.off_x);
-        __bf16* dyb = reinterpret_cast<__bf16*>(ws + f.off_dy);
+        const __bf16* xb = static_cast<const __bf16*>(x_bf16);
+        const __bf16* dyb = static_cast<const __bf16*>(dy_bf16);
         float* slab = reinterpret_cast<float*>(ws + f.off_slab);
         const long long slab_stride = (long long)(16 * c_in + 1) * c_out;
-        int rc = launch_cvt_bf16(x, xb, (int64_t)batch * height * width * c_in, zeros, st0);
-        if (rc == VAEK_OK) rc = launch_cvt_bf16(dy, dyb, (int64_t)pixels * c_out, nullptr, st0);
+        int rc = VAEK_OK;
+        if (!xb) {
+            __bf16* mine = reinterpret_cast<__bf16*>(ws + f.off_x);
+            rc = launch_cvt_bf16(x, mine, (int64_t)batch * height * width * c_in, nullptr, st0);
+            xb = mine;
+        }
+        if (rc == VAEK_OK && !dyb) {
+            __bf16* mine = reinterpret_cast<__bf16*>(ws + f.off_dy);
+            rc = launch_cvt_bf16(dy, mine, (int64_t)pixels * c_out, nullptr, st0);
+            dyb = mine;
+        }
+        if (rc == VAEK_OK) rc = launch_cvt_bf16(nullptr, nullptr, 0, zeros, st0);           // the loader's page of zeros
         if (rc == VAEK_OK) rc = launch_hs_conv_dw(xb, dyb, zeros, slab, slab_stride, f.S, f.rps, batch, height, width, c_in, c_out, st0);
         if (rc == VAEK_OK) rc = launch_sum_slabs(slab, slab_stride, f.S, dw, (int64_t)16 * c_in * c_out, st0);
         if (rc == VAEK_OK && dbias) rc = launch_sum_slabs(slab + (long long)16 * c_in * c_out, slab_stride, f.S, dbias, c_out, st0);
@@ -850,8 +872,8 @@ extern "C" int vaek_conv2d_bias_grad(const float* dy, float* dbias, void* worksp
 
 extern "C" int vaek_conv2d_transpose_forward(const float* y, const float* w, const float* bias, const float* mask, float* out,
                                              int32_t batch, int32_t height, int32_t width, int32_t c_in, int32_t c_out, int32_t relu,
-                                             void* workspace, void* stream) {
-    if (!y || !w || !out || batch < 1 || height < 1 || width < 1 || c_in < 1 || c_out < 1) {
+                                             void* workspace, const void* y_bf16, void* out_bf16, void* stream) {
+    if (!y || !w || !out || batch < 1 || height < 1 || width < 1 || c_in < 1 || c_out < 1 || !aligned16(y_bf16) || !aligned16(out_bf16)) {
         set_error("vaek_conv2d_transpose_forward: invalid argument");
         return VAEK_ERR_INVALID;
     }
@@ -864,28 +886,39 @@ extern "C" int vaek_conv2d_transpose_forward(const float* y, const float* w, con
         ThinArgs ta{};                                    // the last layer's shape: a streaming kernel, exact f32
         ta.x = y; ta.w = w; ta.bias = bias; ta.mask = mask; ta.y = out;
         ta.B = batch; ta.H = height; ta.W = width; ta.C = c_in; ta.pixels = 4 * M;
-        ProfScope ps("conv_t_fwd_thin", (hipStream_t)stream);
-        if ((c_in & (c_in - 1)) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0 && (reinterpret_cast<uintptr_t>(mask) & 7) == 0)
-            launch_k(ps, thin_conv_t_fwd4_kernel, dim3((unsigned)std::min<long long>(8192, (M * (c_in / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
-        else
-            launch_k(ps, thin_conv_t_fwd_kernel, dim3((unsigned)std::min<long long>(16384, (4 * M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
-        VAEK_HIP_CHECK(hipGetLastError());
-        return VAEK_OK;
+        {
+            ProfScope ps("conv_t_fwd_thin", (hipStream_t)stream);
+            if ((c_in & (c_in - 1)) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0 && (reinterpret_cast<uintptr_t>(mask) & 7) == 0)
+                launch_k(ps, thin_conv_t_fwd4_kernel, dim3((unsigned)std::min<long long>(8192, (M * (c_in / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
+            else
+                launch_k(ps, thin_conv_t_fwd_kernel, dim3((unsigned)std::min<long long>(16384, (4 * M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
+            VAEK_HIP_CHECK(hipGetLastError());
+        }
+        return out_bf16 ? launch_cvt_bf16(out, static_cast<__bf16*>(out_bf16), 4 * M, nullptr, (hipStream_t)stream) : VAEK_OK;
     }
     if (workspace && aligned16(workspace) && aligned16(y) && aligned16(w) && aligned16(out) && aligned16(mask) && aligned16(bias)) {
         const ConvFFast f = conv_fwd_fast(1, batch, height, width, c_in, c_out);
-        if (f.ok) return conv_forward_fast(1, f, y, w, bias, mask, out, workspace, batch, height, width, c_in, c_out, relu != 0, (hipStream_t)stream);
+        if (f.ok) return conv_forward_fast(1, f, y, w, bias, mask, out, workspace, y_bf16, out_bf16, batch, height, width, c_in, c_out, relu != 0, (hipStream_t)stream);
     }
     g.M = (int)M; g.N = c_out; g.K = 4 * c_in; g.relu = relu;
-    ProfScope ps("conv_t_fwd_bf16", (hipStream_t)stream);
-    launch_k(ps, conv_t_fwd_kernel, dim3((g.N + CBN - 1) / CBN, (g.M + CBM - 1) / CBM, 4), dim3(CNT), 0, (hipStream_t)stream, g);
-    VAEK_HIP_CHECK(hipGetLastError());
-    return VAEK_OK;
+    {
+        ProfScope ps("conv_t_fwd_bf16", (hipStream_t)stream);
+        launch_k(ps, conv_t_fwd_kernel, dim3((g.N + CBN - 1) / CBN, (g.M + CBM - 1) / CBM, 4), dim3(CNT), 0, (hipStream_t)stream, g);
+        VAEK_HIP_CHECK(hipGetLastError());
+    }
+    return out_bf16 ? launch_cvt_bf16(out, static_cast<__bf16*>(out_bf16), 4 * M * c_out, nullptr, (hipStream_t)stream) : VAEK_OK;
+}
+
+extern "C" int vaek_to_bf16(const float* src, void* dst_bf16, int64_t n, void* stream) {
+    if (!src || !dst_bf16 || n < 0 || !aligned16(src) || !aligned16(dst_bf16)) { set_error("vaek_to_bf16: invalid argument"); return VAEK_ERR_INVALID; }
+    return launch_cvt_bf16(src, static_cast<__bf16*>(dst_bf16), n, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int vaek_conv2d_forward(const float* x, const float* w, const float* bias, const float* mask, float* y, int32_t batch,
-                                   int32_t height, int32_t width, int32_t c_in, int32_t c_out, int32_t relu, void* workspace, void* stream) {
-    if (!x || !w || !y || batch < 1 || height < 2 || width < 2 || (height & 1) || (width & 1) || c_in < 1 || c_out < 1) {
+                                   int32_t height, int32_t width, int32_t c_in, int32_t c_out, int32_t relu, void* workspace,
+                                   const void* x_bf16, void* y_bf16, void* stream) {
+    if (!x || !w || !y || batch < 1 || height < 2 || width < 2 || (height & 1) || (width & 1) || c_in < 1 || c_out < 1 || !aligned16(x_bf16) ||
+        !aligned16(y_bf16)) {
         set_error("vaek_conv2d_forward: invalid argument");
         return VAEK_ERR_INVALID;
     }
@@ -898,21 +931,28 @@ extern "C" int vaek_conv2d_forward(const float* x, const float* w, const float* 
         ThinArgs ta{};
         ta.x = x; ta.w = w; ta.bias = bias; ta.mask = mask; ta.y = y;
         ta.B = batch; ta.H = height; ta.W = width; ta.C = c_out; ta.Ho = g.Ho; ta.Wo = g.Wo; ta.pixels = M;
-        ProfScope ps("conv_fwd_thin", (hipStream_t)stream);
-        if (thin_groups_ok(c_out) && aligned16(w) && aligned16(y) && aligned16(mask))
-            launch_k(ps, thin_conv_fwd8_kernel, dim3((unsigned)std::min<long long>(8192, (M * (c_out / 8) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
-        else
-            launch_k(ps, thin_conv_fwd_kernel, dim3((unsigned)std::min<long long>(8192, (M * c_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
-        VAEK_HIP_CHECK(hipGetLastError());
-        return VAEK_OK;
+        const bool by8 = thin_groups_ok(c_out) && aligned16(w) && aligned16(y) && aligned16(mask);
+        {
+            ProfScope ps("conv_fwd_thin", (hipStream_t)stream);
+            if (by8) {
+                ta.y16 = static_cast<__bf16*>(y_bf16);
+                launch_k(ps, thin_conv_fwd8_kernel, dim3((unsigned)std::min<long long>(8192, (M * (c_out / 8) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
+            } else {
+                launch_k(ps, thin_conv_fwd_kernel, dim3((unsigned)std::min<long long>(8192, (M * c_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
+            }
+            VAEK_HIP_CHECK(hipGetLastError());
+        }
+        return y_bf16 && !by8 ? launch_cvt_bf16(y, static_cast<__bf16*>(y_bf16), M * c_out, nullptr, (hipStream_t)stream) : VAEK_OK;
     }
     if (workspace && aligned16(workspace) && aligned16(x) && aligned16(w) && aligned16(y) && aligned16(mask) && aligned16(bias)) {
         const ConvFFast f = conv_fwd_fast(0, batch, height, width, c_in, c_out);
-        if (f.ok) return conv_forward_fast(0, f, x, w, bias, mask, y, workspace, batch, height, width, c_in, c_out, relu != 0, (hipStream_t)stream);
+        if (f.ok) return conv_forward_fast(0, f, x, w, bias, mask, y, workspace, x_bf16, y_bf16, batch, height, width, c_in, c_out, relu != 0, (hipStream_t)stream);
     }
     g.M = (int)M; g.N = c_out; g.K = 16 * c_in; g.relu = relu;
-    ProfScope ps("conv_fwd_bf16", (hipStream_t)stream);
-    launch_k(ps, conv_fwd_kernel, dim3((g.N + CBN - 1) / CBN, (g.M + CBM - 1) / CBM), dim3(CNT), 0, (hipStream_t)stream, g);
-    VAEK_HIP_CHECK(hipGetLastError());
-    return VAEK_OK;
+    {
+        ProfScope ps("conv_fwd_bf16", (hipStream_t)stream);
+        launch_k(ps, conv_fwd_kernel, dim3((g.N + CBN - 1) / CBN, (g.M + CBM - 1) / CBM), dim3(CNT), 0, (hipStream_t)stream, g);
+        VAEK_HIP_CHECK(hipGetLastError());
+    }
+    return y_bf16 ? launch_cvt_bf16(y, static_cast<__bf16*>(y_bf16), M * c_out, nullptr, (hipStream_t)stream) : VAEK_OK;
 }

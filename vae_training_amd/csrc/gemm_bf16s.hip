@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void hs_tn_kernel(const HsDwArgs g) {
 enum { HC_FWD = 0, HC_T = 1 };
 struct HsConvArgs {
     const __bf16* X; const __bf16* Wb; const __bf16* zeros;
-    float* out; const float* bias; const float* mask;
+    float* out; const float* bias; const float* mask; __bf16* out16;     // out16: optional bf16 copy of out (the next layer's operand)
     int relu, H, W, Cin, Cout, M, N, K;       // H, W: the INPUT tensor's spatial size
     int sh_c, hw, wo;                         // log2 C_in; GEMM rows per image and per image row (FWD: Ho Wo, Wo; T: H W, W)
 };
@@ -732,12 +732,14 @@ __global__ __launch_bounds__(64 * WM * WN) void hs_conv_kernel(const HsConvArgs 
                     v.x = k4.x > 0.f ? v.x : 0.f; v.y = k4.y > 0.f ? v.y : 0.f; v.z = k4.z > 0.f ? v.z : 0.f; v.w = k4.w > 0.f ? v.w : 0.f;
                 }
                 *reinterpret_cast<float4*>(g.out + off + col) = v;
+                if (g.out16) *reinterpret_cast<uint2*>(g.out16 + off + col) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
             }
     }
 }
 
 // bf16 [N][K] copy of a float32 [K][N] array (the convolution kernel as the k-contiguous B operand)
-__global__ __launch_bounds__(256) void cvt_bf16_t_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int K, int N) {
+__global__ __launch_bounds__(256) void cvt_bf16_t_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int K, int N, __bf16* zero8) {
+    if (zero8 && blockIdx.x == 0 && threadIdx.x < 8) zero8[threadIdx.x] = (__bf16)0.f;
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e < (long long)K * N) {
         const int n = (int)(e / K), k = (int)(e % K);
@@ -885,7 +887,8 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__
     }
 }
 int launch_cvt_bf16(const float* src, __bf16* dst, int64_t n, __bf16* zero8, hipStream_t st) {
-    if (n <= 0) return VAEK_OK;
+    if (n <= 0 && !zero8) return VAEK_OK;                  // (n == 0 with a zero page: only the page is written)
+    if (n < 0) n = 0;
     ProfScope ps("cvt_bf16", st);
     launch_k(ps, cvt_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256 + 1)), dim3(256), 0, st, src, dst, (long long)n, zero8);
     VAEK_HIP_CHECK(hipGetLastError());
@@ -925,9 +928,9 @@ static int hs_conv_launch(const HsConvArgs& g, hipStream_t st) {
     return VAEK_OK;
 }
 int launch_hs_conv(int mode, const __bf16* x, const __bf16* wb, const __bf16* zeros, const float* bias, const float* mask, float* out,
-                   int batch, int H, int W, int Cin, int Cout, bool relu, hipStream_t st) {
+                   __bf16* out16, int batch, int H, int W, int Cin, int Cout, bool relu, hipStream_t st) {
     HsConvArgs g{};
-    g.X = x; g.Wb = wb; g.zeros = zeros; g.out = out; g.bias = bias; g.mask = mask; g.relu = relu;
+    g.X = x; g.Wb = wb; g.zeros = zeros; g.out = out; g.out16 = out16; g.bias = bias; g.mask = mask; g.relu = relu;
     g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.N = Cout; g.sh_c = 31 - __builtin_clz(Cin);
     if (mode == HC_FWD) { g.hw = (H / 2) * (W / 2); g.wo = W / 2; g.K = 16 * Cin; }
     else { g.hw = H * W; g.wo = W; g.K = 4 * Cin; }
@@ -946,9 +949,9 @@ int launch_hs_conv(int mode, const __bf16* x, const __bf16* wb, const __bf16* ze
     if (Cout % 64 == 0) return hs_conv_launch<HC_T, 64, 2, 2, 32, 4>(g, st);
     return hs_conv_launch<HC_T, 32, 4, 1, 64, 3>(g, st);
 }
-int launch_cvt_bf16_t(const float* src, __bf16* dst, int K, int N, hipStream_t st) {
+int launch_cvt_bf16_t(const float* src, __bf16* dst, int K, int N, __bf16* zero8, hipStream_t st) {
     ProfScope ps("cvt_bf16_t", st);
-    launch_k(ps, cvt_bf16_t_kernel, dim3((unsigned)(((long long)K * N + 255) / 256)), dim3(256), 0, st, src, dst, K, N);
+    launch_k(ps, cvt_bf16_t_kernel, dim3((unsigned)(((long long)K * N + 255) / 256)), dim3(256), 0, st, src, dst, K, N, zero8);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
 }
