@@ -719,7 +719,7 @@ static ConvWFast conv_wgrad_fast(long long batch, int H, int W, int Cin, int Cou
     f.ok = Cin % 8 == 0 && Cout % 8 == 0 && (hw & (hw - 1)) == 0 && (Wo & (Wo - 1)) == 0 && pixels >= 64 && pixels < 0x7fffffffll;
     if (!f.ok) return f;
     const long long tiles = (long long)((16 * Cin + 127) / 128) * ((Cout + 127) / 128);
-    long long S = std::max(1ll, 2048 / tiles);
+    long long S = std::max(1ll, 1024 / tiles);            // ~1024 workgroups; more splits only add slab traffic (2 x S x slab bytes)
     S = std::min(S, std::max(1ll, pixels / 512));
     f.rps = (int)(((pixels + S - 1) / S + 63) / 64 * 64);
     f.S = (int)((pixels + f.rps - 1) / f.rps);

@@ -613,9 +613,10 @@ __global__ __launch_bounds__(64 * WM * WN) void hs_conv_kernel(const HsConvArgs 
     constexpr int A_PASSES = BM * CPR / NTH, B_PASSES = BN * CPR / NTH, P = A_PASSES + B_PASSES;
     static_assert(BM * CPR % NTH == 0 && BN * CPR % NTH == 0 && B_PASSES >= 1, "whole staging passes");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const unsigned tiles_n = g.N / BN;
-    const int m0 = (int)(blockIdx.x / tiles_n) * BM, n0 = (int)(blockIdx.x % tiles_n) * BN;
-    const int pp = MODE == HC_T ? (int)(blockIdx.y >> 1) : 0, qq = MODE == HC_T ? (int)(blockIdx.y & 1) : 0;
+    // T: the four parity classes of a tile are neighbours in the launch order -- they read the same input pixels (one HBM read, three L2 hits)
+    const unsigned tiles_n = g.N / BN, bid = MODE == HC_T ? blockIdx.x >> 2 : blockIdx.x, cls = MODE == HC_T ? blockIdx.x & 3 : 0;
+    const int m0 = (int)(bid / tiles_n) * BM, n0 = (int)(bid % tiles_n) * BN;
+    const int pp = (int)(cls >> 1), qq = (int)(cls & 1);
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wv / WN, wn = wv % WN;
@@ -677,6 +678,30 @@ __global__ __launch_bounds__(64 * WM * WN) void hs_conv_kernel(const HsConvArgs 
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
+    // the epilogue's row offsets; with a small register tile the relu mask is fetched NOW, under the whole main loop (a workgroup of
+    // these shapes sees only 4-16 k-tiles: a mask fetched in the epilogue is one more exposed HBM round trip per tile)
+    const int nbase = n0 + wn * (BN / WN);
+    constexpr bool kEarlyMask = TM * TN <= 2;
+    long long offs[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = min(m0 + wm * (BM / WM) + i * 32 + r, g.M - 1);
+        if (MODE == HC_FWD) offs[i] = (long long)m * g.N;
+        else {
+            const int n = m / g.hw, ij = m % g.hw, ii = ij / g.wo, jj = ij % g.wo;
+            offs[i] = (((long long)n * 2 * g.H + 2 * ii + pp) * 2 * g.W + 2 * jj + qq) * g.N;
+        }
+    }
+    float4 mk[kEarlyMask ? TM : 1][kEarlyMask ? TN : 1][4];
+    if (kEarlyMask && g.mask) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mk[i][j][q] = *reinterpret_cast<const float4*>(g.mask + offs[i] + nbase + 32 * j + 8 * q + 4 * h);
+    }
+
     const int nt = g.K / BK;
 #pragma unroll
     for (int q = 0; q < NS - 1; ++q) if (q < nt) stage(q, q);
@@ -704,18 +729,12 @@ __global__ __launch_bounds__(64 * WM * WN) void hs_conv_kernel(const HsConvArgs 
     }
 
     // ---- epilogue: register 4 q + p of tile (i, j) = C[row][nbase + 32 j + 8 q + 4 h + p]
-    const int nbase = n0 + wn * (BN / WN);
     const float floor_v = g.relu ? 0.f : -__builtin_huge_valf();
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * (BM / WM) + i * 32 + r;
         if (m >= g.M) continue;
-        long long off;
-        if (MODE == HC_FWD) off = (long long)m * g.N;
-        else {
-            const int n = m / g.hw, ij = m % g.hw, ii = ij / g.wo, jj = ij % g.wo;
-            off = (((long long)n * 2 * g.H + 2 * ii + pp) * 2 * g.W + 2 * jj + qq) * g.N;
-        }
+        const long long off = offs[i];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -728,7 +747,7 @@ __global__ __launch_bounds__(64 * WM * WN) void hs_conv_kernel(const HsConvArgs 
                 }
                 v.x = fmaxf(v.x, floor_v); v.y = fmaxf(v.y, floor_v); v.z = fmaxf(v.z, floor_v); v.w = fmaxf(v.w, floor_v);
                 if (g.mask) {
-                    const float4 k4 = *reinterpret_cast<const float4*>(g.mask + off + col);
+                    const float4 k4 = kEarlyMask ? mk[i][j][q] : *reinterpret_cast<const float4*>(g.mask + off + col);
                     v.x = k4.x > 0.f ? v.x : 0.f; v.y = k4.y > 0.f ? v.y : 0.f; v.z = k4.z > 0.f ? v.z : 0.f; v.w = k4.w > 0.f ? v.w : 0.f;
                 }
                 *reinterpret_cast<float4*>(g.out + off + col) = v;
@@ -923,7 +942,7 @@ static int hs_conv_launch(const HsConvArgs& g, hipStream_t st) {
     static thread_local bool attr_set = false;
     if (!attr_set) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
     ProfScope ps(MODE == HC_FWD ? "conv_fwd_bf16s" : "conv_t_fwd_bf16s", st);
-    launch_k(ps, fn, dim3((unsigned)(((g.M + 127) / 128) * (g.N / BN)), MODE == HC_T ? 4u : 1u), dim3(64 * WM * WN), lds, st, g);
+    launch_k(ps, fn, dim3((unsigned)(((g.M + 127) / 128) * (g.N / BN)) * (MODE == HC_T ? 4u : 1u)), dim3(64 * WM * WN), lds, st, g);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
 }
@@ -943,11 +962,11 @@ int launch_hs_conv(int mode, const __bf16* x, const __bf16* wb, const __bf16* ze
     if (mode == HC_FWD) {
         if (Cout % 128 == 0) return hs_conv_launch<HC_FWD, 128, 2, 2, 32, 3>(g, st);
         if (Cout % 64 == 0) return hs_conv_launch<HC_FWD, 64, 2, 2, 32, 4>(g, st);
-        return hs_conv_launch<HC_FWD, 32, 4, 1, 64, 3>(g, st);
+        return hs_conv_launch<HC_FWD, 32, 2, 1, 32, 4>(g, st);
     }
     if (Cout % 128 == 0) return hs_conv_launch<HC_T, 128, 2, 2, 32, 3>(g, st);
     if (Cout % 64 == 0) return hs_conv_launch<HC_T, 64, 2, 2, 32, 4>(g, st);
-    return hs_conv_launch<HC_T, 32, 4, 1, 64, 3>(g, st);
+    return hs_conv_launch<HC_T, 32, 2, 1, 32, 4>(g, st);
 }
 int launch_cvt_bf16_t(const float* src, __bf16* dst, int K, int N, __bf16* zero8, hipStream_t st) {
     ProfScope ps("cvt_bf16_t", st);
