@@ -771,7 +771,7 @@ extern "C" int vaek_conv2d_weight_grad_workspace(int32_t batch, int32_t height, 
     const int M = 16 * c_in + 1;
     const ConvWFast f = conv_wgrad_fast(batch, height, width, c_in, c_out);
     *bytes = f.ok ? f.bytes : (size_t)conv_wgrad_splits(pixels, M, c_out) * M * c_out * sizeof(float);
-    if (c_in == 1 && thin_channels_ok(c_out)) *bytes = std::max(*bytes, (size_t)kThinWgradBlocks * 17 * c_out * sizeof(float));
+    if (c_in == 1 && thin_channels_ok(c_out)) *bytes = std::max(*bytes, (size_t)(kThinWgradBlocks + 1) * 17 * c_out * sizeof(float));
     return VAEK_OK;
 }
 
@@ -801,8 +801,10 @@ extern "C" int vaek_conv2d_weight_grad(const float* x, const float* dy, float* d
             else launch_k(ps, thin_conv_wgrad_kernel, dim3(nb), dim3(256), 0, st0, ta, part);
             VAEK_HIP_CHECK(hipGetLastError());
         }
-        int rc = launch_sum_slabs(part, (int64_t)17 * c_out, nb, dw, (int64_t)16 * c_out, st0);
-        if (rc == VAEK_OK && dbias) rc = launch_sum_slabs(part + 16 * c_out, (int64_t)17 * c_out, nb, dbias, c_out, st0);
+        float* dwb = part + (size_t)kThinWgradBlocks * 17 * c_out;      // [17][c_out] behind the block partials: one grouped sum for kernel and bias
+        int rc = launch_sum_slabs_inplace(part, (int64_t)17 * c_out, nb, dwb, (int64_t)17 * c_out, st0);
+        if (rc == VAEK_OK) rc = launch_sum_slabs(dwb, 0, 1, dw, (int64_t)16 * c_out, st0);                  // (a "sum" of one slab: the copy)
+        if (rc == VAEK_OK && dbias) rc = launch_sum_slabs(dwb + 16 * c_out, 0, 1, dbias, c_out, st0);
         return rc;
     }
     const ConvWFast f = conv_wgrad_fast(batch, height, width, c_in, c_out);
@@ -860,7 +862,7 @@ extern "C" int vaek_conv2d_bias_grad(const float* dy, float* dbias, void* worksp
             launch_k(ps, conv_colsum4_kernel, dim3(S4), dim3(256), 0, st, reinterpret_cast<const float4*>(dy), static_cast<float*>(workspace), n4, (int)c, chunk);
             VAEK_HIP_CHECK(hipGetLastError());
         }
-        return launch_sum_slabs(static_cast<const float*>(workspace), c, S4, dbias, c, st);
+        return launch_sum_slabs_inplace(static_cast<float*>(workspace), c, S4, dbias, c, st);
     }
     {
         ProfScope ps("conv_bias_grad", st);

@@ -472,6 +472,37 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* slabs, long
     out[i] = g;
 }
 
+// Many slabs, few outputs (the streaming convolution kernels' 1024 block partials of 544 floats; a bias gradient's 512 partials of one
+// float): sum_slabs_kernel would be 2 workgroups walking 1024 dependent rounds.  First every group of 32 consecutive slabs is summed,
+// ascending, into the group's FIRST slab (a thread reads only its own element of its own group's slabs before it writes), then the
+// group sums are summed ascending: a fixed order again.
+__global__ __launch_bounds__(256) void sum_slab_groups_kernel(float* slabs, long long stride, int S, int GS, long long n) {
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x, i = id % n;
+    const int g = (int)(id / n), s_lo = g * GS, s_hi = min(S, s_lo + GS);
+    if (s_lo >= S) return;
+    float acc = 0.f;
+    for (int s0 = s_lo; s0 < s_hi; s0 += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = slabs[(long long)min(s0 + u, s_hi - 1) * stride + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += s0 + u < s_hi ? t[u] : 0.f;
+    }
+    slabs[(long long)s_lo * stride + i] = acc;
+}
+int launch_sum_slabs_inplace(float* slabs, int64_t stride, int S, float* out, int64_t n, hipStream_t st) {
+    constexpr int GS = 32;
+    if (n <= 0) return VAEK_OK;
+    if (S < 4 * GS || n > 65536) return launch_sum_slabs(slabs, stride, S, out, n, st);
+    const int G = (S + GS - 1) / GS;
+    {
+        ProfScope ps("sum_slab_groups", st);
+        launch_k(ps, sum_slab_groups_kernel, dim3((unsigned)((n * G + 255) / 256)), dim3(256), 0, st, slabs, (long long)stride, S, GS, (long long)n);
+        VAEK_HIP_CHECK(hipGetLastError());
+    }
+    return launch_sum_slabs(slabs, stride * GS, G, out, n, st);
+}
+
 int launch_sum_slabs(const float* slabs, int64_t stride, int S, float* out, int64_t n, hipStream_t st) {
     if (n <= 0) return VAEK_OK;
     ProfScope ps("sum_slabs", st);

@@ -232,6 +232,7 @@ int launch_eval_out4(const float* partial, int S, const float* params, int64_t o
                      int64_t off_eps, int L, int D, float eps_cli, float rows, float inv_bt, float* out4,
                      hipStream_t st);
 int launch_sum_slabs(const float* slabs, int64_t stride, int S, float* out, int64_t n, hipStream_t st);
+int launch_sum_slabs_inplace(float* slabs, int64_t stride, int S, float* out, int64_t n, hipStream_t st);   // many slabs, few outputs; clobbers the slabs
 #ifdef __HIPCC__
 int launch_cvt_bf16(const float* src, __bf16* dst, int64_t n, __bf16* zero8, hipStream_t st);
 int launch_cvt_bf16_t(const float* src, __bf16* dst, int K, int N, __bf16* zero8, hipStream_t st);
