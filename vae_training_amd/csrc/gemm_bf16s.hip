@@ -960,13 +960,13 @@ int launch_hs_conv(int mode, const __bf16* x, const __bf16* wb, const __bf16* ze
     }
     g.M = (int)M;
     if (mode == HC_FWD) {
-        if (Cout % 128 == 0) return hs_conv_launch<HC_FWD, 128, 2, 2, 32, 3>(g, st);
+        if (Cout % 128 == 0) return hs_conv_launch<HC_FWD, 128, 2, 2, 64, 2>(g, st);
         if (Cout % 64 == 0) return hs_conv_launch<HC_FWD, 64, 2, 2, 64, 3>(g, st);
-        return hs_conv_launch<HC_FWD, 32, 2, 1, 32, 4>(g, st);
+        return hs_conv_launch<HC_FWD, 32, 4, 1, 64, 3>(g, st);
     }
-    if (Cout % 128 == 0) return hs_conv_launch<HC_T, 128, 2, 2, 32, 3>(g, st);
+    if (Cout % 128 == 0) return hs_conv_launch<HC_T, 128, 2, 2, 64, 2>(g, st);
     if (Cout % 64 == 0) return hs_conv_launch<HC_T, 64, 2, 2, 64, 3>(g, st);
-    return hs_conv_launch<HC_T, 32, 2, 1, 32, 4>(g, st);
+    return hs_conv_launch<HC_T, 32, 4, 1, 64, 3>(g, st);
 }
 int launch_cvt_bf16_t(const float* src, __bf16* dst, int K, int N, __bf16* zero8, hipStream_t st) {
     ProfScope ps("cvt_bf16_t", st);
