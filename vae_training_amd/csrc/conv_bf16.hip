@@ -699,10 +699,56 @@ __global__ __launch_bounds__(256) void thin_conv_wgrad8_kernel(const ThinArgs g,
     for (int e = threadIdx.x; e < 17 * C; e += 256)
         part[(long long)blockIdx.x * 17 * C + e] = (red[e] + red[17 * C + e]) + (red[2 * 17 * C + e] + red[3 * 17 * C + e]);
 }
+// The kernel gradient again, on the f32 matrix cores (C a multiple of 32, power-of-two output sizes): it IS a GEMM with M = 16 taps + a
+// row of ones, N = C, K = pixels; v_mfma_f32_32x32x2_f32 takes two pixels per instruction -- lane (i, k) supplies x at tap i of pixel k
+// (one gathered dword), lane (j, k) supplies dy[pixel k][j] (a coalesced row) -- and the 17 x 8 accumulators per thread of the VALU
+// form become 16 registers per lane, so many more waves stream at once.  blockIdx.y = the block of 32 channels.
+__global__ __launch_bounds__(256) void thin_conv_wgrad_mfma_kernel(const ThinArgs g, float* part, const int sh_hw, const int sh_w) {
+    __shared__ float red[4][17 * 32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, k = lane >> 5, c0 = blockIdx.y * 32;
+    const int kh = (i >> 2) & 3, kw = i & 3;
+    f32x16 acc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+    const long long pairs = (g.pixels + 1) / 2, per = (pairs + gridDim.x - 1) / gridDim.x;
+    const long long q0 = blockIdx.x * per, q1 = min(pairs, q0 + per);
+    auto a_val = [&](long long p, bool live) -> float {     // x at tap i of pixel p (ones row 16, zero rows above)
+        const int n = (int)(p >> sh_hw), ij = (int)(p & ((1 << sh_hw) - 1)), yy = 2 * (ij >> sh_w) - 1 + kh, xx = 2 * (ij & ((1 << sh_w) - 1)) - 1 + kw;
+        const bool in = live && i < 16 && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+        const float v = g.x[((long long)n * g.H + min(max(yy, 0), g.H - 1)) * g.W + min(max(xx, 0), g.W - 1)];
+        return in ? v : (live && i == 16 ? 1.f : 0.f);
+    };
+    for (long long q = q0 + wave; q < q1; q += 32) {       // 4 waves x 8 pairs in flight per wave (2 KB of dy: HBM needs ~16 MB in flight chip-wide)
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long qq = q + 4 * u, p = min(2 * qq + k, g.pixels - 1);
+            const bool live = qq < q1 && 2 * qq + k < g.pixels;
+            av[u] = a_val(p, live);
+            const float d = g.mask[p * g.C + c0 + i];
+            bv[u] = live ? d : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc[u & 1], 0, 0, 0);
+    }
+    // register r of a lane: row (r & 3) + 8 (r >> 2) + 4 k (the tap), column i (the channel)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * k;
+        if (row < 17) red[wave][row * 32 + i] = acc[0][r] + acc[1][r];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 17 * 32; e += 256) {
+        const int row = e >> 5, col = e & 31;
+        part[(long long)blockIdx.x * 17 * g.C + row * g.C + c0 + col] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    }
+}
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static bool thin_channels_ok(int c) { return c >= 1 && c <= 256 && 256 % c == 0; }
 static bool thin_groups_ok(int c) { return c % 8 == 0 && c <= 256 && 256 % c == 0; }     // c / 8 divides 32: lanes of a group stay in a wave
-constexpr int kThinWgradBlocks = 1024;
+constexpr int kThinWgradBlocks = 2048;
 
 }  // namespace vaek
 
@@ -797,7 +843,10 @@ extern "C" int vaek_conv2d_weight_grad(const float* x, const float* dy, float* d
         const int nb = (int)std::min<long long>(kThinWgradBlocks, (pixels + 255) / 256);
         {
             ProfScope ps("conv_wgrad_thin", st0);
-            if (thin_groups_ok(c_out) && aligned16(dy)) launch_k(ps, thin_conv_wgrad8_kernel, dim3(nb), dim3(256), (size_t)4 * 17 * c_out * sizeof(float), st0, ta, part);
+            const int hw = g.Ho * g.Wo;
+            if (c_out % 32 == 0 && (hw & (hw - 1)) == 0 && (g.Wo & (g.Wo - 1)) == 0)
+                launch_k(ps, thin_conv_wgrad_mfma_kernel, dim3(nb, c_out / 32), dim3(256), 0, st0, ta, part, 31 - __builtin_clz(hw), 31 - __builtin_clz(g.Wo));
+            else if (thin_groups_ok(c_out) && aligned16(dy)) launch_k(ps, thin_conv_wgrad8_kernel, dim3(nb), dim3(256), (size_t)4 * 17 * c_out * sizeof(float), st0, ta, part);
             else launch_k(ps, thin_conv_wgrad_kernel, dim3(nb), dim3(256), 0, st0, ta, part);
             VAEK_HIP_CHECK(hipGetLastError());
         }
