@@ -44,6 +44,29 @@ def test_dense_fwd_bwd(rows, n_in, n_out, relu):
         assert rel_err(host(gdwb), dwb) <= 5e-6
 
 
+@pytest.mark.parametrize("rows,n_wide,n_thin", [(8192, 1024, 20), (8211, 2048, 32), (9001, 1152, 7), (16384, 4096, 20)])
+def test_tall_skinny_streaming_dense(rows, n_wide, n_thin):
+    """The long-reduction / skinny-output shapes (C4's 4096 -> 20 encoder forward with the reparameterisation, and the decoder's input
+    gradient) run on ts_gemm_kernel (gemm_f32.hip): four waves split K, partial tiles summed in a fixed order.  Ragged row counts,
+    thin sides off the 4-grid, accumulate."""
+    eng = _eng()
+    rng = np.random.default_rng(rows + n_wide + n_thin)
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    x = f32(rng.standard_normal((rows, n_wide))); w = f32(rng.standard_normal((n_wide, n_thin)) / np.sqrt(n_wide))
+    b = f32(rng.standard_normal(n_thin)); z1 = f32(rng.standard_normal((rows, n_thin))); lv = f32(0.3 * rng.standard_normal(n_thin))
+    mu, samples = eng.dense_fwd_reparam(dev(x), dev(w), dev(b), dev(z1), dev(lv))
+    want_mu = x @ w + b
+    assert rel_err(host(mu), want_mu) <= 2e-6 and rel_err(host(samples), want_mu + np.exp(lv / 2) * z1) <= 2e-6
+    mu2, _ = eng.dense_fwd_reparam(dev(x), dev(w), dev(b), dev(z1), dev(lv))
+    assert torch.equal(mu, mu2)                                   # fixed-order sums: bitwise repeatable
+    wd = f32(rng.standard_normal((n_thin, n_wide)) / np.sqrt(n_wide))      # a decoder kernel [thin, wide]; dy [rows, wide]
+    dx = x @ wd.T
+    gdx = eng.dense_bwd_dx(dev(x), dev(wd))
+    assert rel_err(host(gdx), dx) <= 2e-6
+    gdx2 = eng.dense_bwd_dx(dev(x), dev(wd), out=gdx.clone(), accumulate=True)
+    assert rel_err(host(gdx2), 2 * dx) <= 2e-6
+
+
 @pytest.mark.parametrize("sig", [False, True])
 @pytest.mark.parametrize("rows,D,L", [(5, 3, 2), (256, 12, 20), (1000, 7, 6), (777, 33, 9)])
 def test_elbo_block(rows, D, L, sig):

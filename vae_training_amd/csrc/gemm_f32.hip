@@ -326,6 +326,84 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const GemmArgs g) {
     }
 }
 
+// ---- tall-skinny streaming form: C[M, N <= 32] = A[M, K] . B[K, N] with a long K (C4's 4096 -> 20 encoder forward and the decoder's
+// input gradient; the conv VAE's 4096 -> 32 bottleneck).  The tiled kernel above gives such a layer ONE 128 x 32 tile = four waves
+// per CU, far too few bytes in flight for an HBM stream (2.6 TB/s).  Here a workgroup owns 32 rows and its four waves SPLIT K: no
+// LDS staging, no barrier in the loop -- lane (row, h) streams its own row with 16-byte loads (k = k0 + 8 u + 4 h .. + 3 pairs with
+// the other half-wave's k + 4: any pairing works as long as A and B agree), 32 rows per workgroup = 4x the workgroups, and the four
+// partial tiles meet through LDS in a fixed order before the epilogue.
+struct TsArgs {
+    const float* A; const float* B; float* C; float* C2; const float* bias; const float* aux; const float* lv;
+    int M, N, K, lda, ldb, ldc, accumulate;
+};
+template <int EPI, bool B_KCONT>
+__global__ __launch_bounds__(256) void ts_gemm_kernel(const TsArgs g) {
+    __shared__ float red[4][32][33];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * 32, row = min(m0 + i, g.M - 1), col = min(i, g.N - 1);
+    const int kq = g.K / 4, kbeg = wave * kq;                 // K % 32 == 0: every wave's range is whole 8-deep steps
+    const float* pa = g.A + (long long)row * g.lda + kbeg + 4 * h;
+    const float* pb = B_KCONT ? g.B + (long long)col * g.ldb + kbeg + 4 * h : g.B + (long long)(kbeg + 4 * h) * g.ldb + col;
+    f32x16 acc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+    constexpr int U = 4;                                      // 16-byte loads of A per lane and trip: 32 k per trip
+    float4 a[2][U], b[2][U];
+    auto fetch = [&](int k, int set) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            a[set][u] = *reinterpret_cast<const float4*>(pa + k + 8 * u);
+            if (B_KCONT) b[set][u] = *reinterpret_cast<const float4*>(pb + k + 8 * u);
+            else {
+                const float* q = pb + (long long)(k + 8 * u) * g.ldb;
+                b[set][u] = make_float4(q[0], q[g.ldb], q[2 * g.ldb], q[3 * g.ldb]);
+            }
+        }
+    };
+    auto multiply = [&](int set) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][u].x, b[set][u].x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][u].y, b[set][u].y, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][u].z, b[set][u].z, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][u].w, b[set][u].w, acc[1], 0, 0, 0);
+        }
+    };
+    fetch(0, 0);
+    for (int k = 0; k < kq; k += 2 * 8 * U) {                 // two trips per iteration: the other set loads under this one's MFMAs
+        if (k + 8 * U < kq) fetch(k + 8 * U, 1);
+        multiply(0);
+        if (k + 8 * U < kq) {
+            if (k + 2 * 8 * U < kq) fetch(k + 2 * 8 * U, 0);
+            multiply(1);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][i] = acc[0][r] + acc[1][r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * g.N; e += 256) {
+        const int rr = e / g.N, c = e % g.N, m = m0 + rr;
+        if (m >= g.M) continue;
+        float v = (red[0][rr][c] + red[1][rr][c]) + (red[2][rr][c] + red[3][rr][c]);
+        const long long o = (long long)m * g.ldc + c;
+        if (EPI == EPI_REPARAM) {
+            v += g.bias ? g.bias[c] : 0.f;
+            g.C[o] = v;
+            g.C2[o] = v + expf(0.5f * g.lv[c]) * g.aux[o];
+        } else {                                              // EPI_DX without a relu mask
+            if (g.accumulate) v += g.C[o];
+            g.C[o] = v;
+        }
+    }
+}
+// shapes the streaming form takes: a skinny output, a long reduction in whole 32-deep trips per wave, enough rows to fill the chip
+static bool ts_shape_ok(int M, int N, int K, int lda, int ldb, const void* A, const void* B, bool b_kcont) {
+    return N <= 32 && K >= 1024 && K % 128 == 0 && M >= 2048 && lda % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
+           (!b_kcont || (ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0));
+}
+
 static thread_local int g_last_bm = 0, g_last_nbx = 0;      // tile rows / tile columns of the last launch (ELBO partials)
 
 template <typename TA, typename TB, typename TC, typename TX, bool A_KCONT, bool B_KCONT, int EPI, int WM, int WN, int BK, int TM = 1, int TN = 1>
@@ -400,6 +478,15 @@ int launch_dense_fwd_elbo(const float* h, const float* w, const float* b, float*
 
 int launch_dense_fwd_reparam(const float* x, const float* w, const float* b, float* mu, float* samples,
                              const float* z1, const float* lv, int rows, int n_in, int n_out, hipStream_t st) {
+    if (ts_shape_ok(rows, n_out, n_in, n_in, n_out, x, w, false)) {
+        TsArgs t{};
+        t.A = x; t.B = w; t.C = mu; t.C2 = samples; t.bias = b; t.aux = z1; t.lv = lv;
+        t.M = rows; t.N = n_out; t.K = n_in; t.lda = n_in; t.ldb = n_out; t.ldc = n_out;
+        ProfScope ps("gemm_f32_fwd_reparam_ts", st);
+        launch_k(ps, (ts_gemm_kernel<EPI_REPARAM, false>), dim3((rows + 31) / 32), dim3(256), 0, st, t);
+        VAEK_HIP_CHECK(hipGetLastError());
+        return VAEK_OK;
+    }
     GemmArgs g{};
     g.A = x; g.B = w; g.C = mu; g.C2 = samples; g.aux = z1; g.lv = lv;
     g.M = rows; g.N = n_out; g.K = n_in; g.lda = n_in; g.ldb = n_out; g.ldc = n_out; g.bias = b;
@@ -409,6 +496,14 @@ int launch_dense_fwd_reparam(const float* x, const float* w, const float* b, flo
 int launch_dense_bwd_dx(const float* dy, const float* w, const float* x_post, float* dx, int rows,
                         int n_in, int n_out, bool relu, bool accumulate, hipStream_t st) {
     // dX[rows, n_in] = dY[rows, n_out] . W^T ; B(k = out index, j = in index) = W[j*n_out + k]
+    if (!(relu && x_post) && ts_shape_ok(rows, n_in, n_out, n_out, n_out, dy, w, true)) {
+        TsArgs t{};
+        t.A = dy; t.B = w; t.C = dx; t.M = rows; t.N = n_in; t.K = n_out; t.lda = n_out; t.ldb = n_out; t.ldc = n_in; t.accumulate = accumulate;
+        ProfScope ps("gemm_f32_dx_ts", st);
+        launch_k(ps, (ts_gemm_kernel<EPI_DX, true>), dim3((rows + 31) / 32), dim3(256), 0, st, t);
+        VAEK_HIP_CHECK(hipGetLastError());
+        return VAEK_OK;
+    }
     GemmArgs g{};
     g.A = dy; g.B = w; g.C = dx; g.M = rows; g.N = n_in; g.K = n_out;
     g.lda = n_out; g.ldb = n_out; g.ldc = n_in; g.aux = x_post; g.relu = relu && x_post != nullptr;
