@@ -745,6 +745,57 @@ __global__ __launch_bounds__(256) void thin_conv_wgrad_mfma_kernel(const ThinArg
         part[(long long)blockIdx.x * 17 * g.C + row * g.C + c0 + col] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
     }
 }
+// The C_in = 1 forward on the f32 matrix cores (C a multiple of 32, power-of-two output sizes): rows = 32 pixels, k = the 16 taps,
+// columns = 32 channels; 8 gathered dwords per lane feed 8 v_mfma_f32_32x32x2_f32, the 16 x 32 weights of the channel block sit in 8
+// registers, and a result register is one pixel's 32 channels across 32 lanes -- 128-byte rows for the stores, the mask and the bf16
+// copy.  ~50 VGPRs instead of 190: four times the waves, i.e. the bytes in flight this HBM-bound layer was missing.
+__global__ __launch_bounds__(256) void thin_conv_fwd_mfma_kernel(const ThinArgs g, const int relu, const int sh_hw, const int sh_w) {
+    const int lane = threadIdx.x & 63, i = lane & 31, kk = lane >> 5, c0 = blockIdx.y * 32;
+    float bw[8];
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) bw[s2] = g.w[(2 * s2 + kk) * g.C + c0 + i];
+    const float bias = g.bias ? g.bias[c0 + i] : 0.f;
+    const long long tiles = (g.pixels + 31) / 32, wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+    for (long long tile = wave_id; tile < tiles; tile += nwaves) {
+        const long long p0 = tile * 32, p = min(p0 + i, g.pixels - 1);
+        const int n = (int)(p >> sh_hw), ij = (int)(p & ((1 << sh_hw) - 1)), y0 = 2 * (ij >> sh_w) - 1, x0 = 2 * (ij & ((1 << sh_w) - 1)) - 1 + kk;
+        const float* img = g.x + (long long)n * g.H * g.W;
+        float av[8];
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {                   // tap 2 s2 + kk: kh = s2 >> 1, kw = 2 (s2 & 1) + kk
+            const int yy = y0 + (s2 >> 1), xx = x0 + 2 * (s2 & 1);
+            const bool in = yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+            const float v = img[(long long)min(max(yy, 0), g.H - 1) * g.W + min(max(xx, 0), g.W - 1)];
+            av[s2] = in ? v : 0.f;
+        }
+        float mk[16];
+        if (g.mask) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mk[r] = g.mask[min(p0 + (r & 3) + 8 * (r >> 2) + 4 * kk, g.pixels - 1) * g.C + c0 + i];
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bias;
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bw[s2], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long q = p0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            float v = acc[r];
+            if (relu) v = fmaxf(v, 0.f);
+            if (g.mask) v = mk[r] > 0.f ? v : 0.f;
+            const float nb = __shfl_down(v, 1, 64);        // the odd neighbour's channel: even lanes store bf16 pairs
+            if (q < g.pixels) {
+                g.y[q * g.C + c0 + i] = v;
+                if (g.y16 && !(i & 1)) {
+                    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+                    const bf16x2_t pr = {(__bf16)v, (__bf16)nb};
+                    *reinterpret_cast<bf16x2_t*>(g.y16 + q * g.C + c0 + i) = pr;
+                }
+            }
+        }
+    }
+}
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static bool thin_channels_ok(int c) { return c >= 1 && c <= 256 && 256 % c == 0; }
 static bool thin_groups_ok(int c) { return c % 8 == 0 && c <= 256 && 256 % c == 0; }     // c / 8 divides 32: lanes of a group stay in a wave
@@ -985,7 +1036,12 @@ extern "C" int vaek_conv2d_forward(const float* x, const float* w, const float* 
         const bool by8 = thin_groups_ok(c_out) && aligned16(w) && aligned16(y) && aligned16(mask);
         {
             ProfScope ps("conv_fwd_thin", (hipStream_t)stream);
-            if (by8) {
+            const int hw = g.Ho * g.Wo;
+            if (by8 && c_out % 32 == 0 && (hw & (hw - 1)) == 0 && (g.Wo & (g.Wo - 1)) == 0) {
+                ta.y16 = static_cast<__bf16*>(y_bf16);
+                launch_k(ps, thin_conv_fwd_mfma_kernel, dim3((unsigned)std::min<long long>(8192, (M / 32 + 3) / 4 + 1), c_out / 32), dim3(256), 0, (hipStream_t)stream,
+                         ta, (int)relu, 31 - __builtin_clz(hw), 31 - __builtin_clz(g.Wo));
+            } else if (by8) {
                 ta.y16 = static_cast<__bf16*>(y_bf16);
                 launch_k(ps, thin_conv_fwd8_kernel, dim3((unsigned)std::min<long long>(8192, (M * (c_out / 8) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
             } else {
