@@ -103,7 +103,7 @@ struct vaek_ctx {
     int S, rows_per_split, Se, rows_per_esplit;
     bool fused;                      // fused small-model path available and selected
     // workspace layout (bytes)
-    size_t ws_samples, ws_dsamp, ws_gbuf0, ws_gbuf1, ws_slabs, ws_epart, ws_rpart, ws_eblk, ws_fused, ws_wb16, ws_sk16, ws_skpart, ws_lin, ws_total;
+    size_t ws_samples, ws_dsamp, ws_gbuf0, ws_gbuf1, ws_slabs, ws_epart, ws_epart_blk, ws_rpart, ws_eblk, ws_fused, ws_wb16, ws_sk16, ws_skpart, ws_lin, ws_total;
     int max_width;
     int n_cu;
     vaek::Comm comm;
