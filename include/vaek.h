@@ -121,6 +121,12 @@ int vaek_elbo_fwd_bwd(vaek_ctx* ctx, const float* x, const float* x_hat_lin, con
                       const float* z2, const float* mu, const float* logvar_e, float eps,
                       float* d_lin, float* d_sig, float* out4, int32_t rows, int32_t data_dim,
                       int32_t latent_dim, int64_t batch_total, void* workspace, void* stream);
+/* The same with eps = eps_param_dev[0] * eps_scale read ON THE DEVICE (the tunable decoder variance of networks.py:70-71 is a
+ * parameter: no host read, so a step built from the block entry points can be captured into a hipGraph). */
+int vaek_elbo_fwd_bwd_dev(vaek_ctx* ctx, const float* x, const float* x_hat_lin, const float* x_hat_sig,
+                          const float* z2, const float* mu, const float* logvar_e, const float* eps_param_dev, float eps_scale,
+                          float* d_lin, float* d_sig, float* out4, int32_t rows, int32_t data_dim,
+                          int32_t latent_dim, int64_t batch_total, void* workspace, void* stream);
 /* flax.optim.Adam.apply_gradient, networks.py:100 (beta1 .9, beta2 .999, eps 1e-8).
  * `step_dev` (device int32, may be NULL) holds t of THIS update (1-based) when non-NULL,
  * otherwise `step` is used.  grad_scale multiplies the gradient first (1/world for means). */

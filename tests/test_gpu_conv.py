@@ -366,6 +366,36 @@ def test_conv_vae_loss_and_every_gradient_leaf(size, widths, L, B, tdv, monkeypa
         assert np.sqrt(np.mean((got - want) ** 2)) <= 0.3 * (np.sqrt(np.mean(want ** 2)) + 1e-30), name
 
 
+def test_conv_vae_graph_replay_is_the_eager_step():
+    """ConvVAE.capture: the step as a hipGraph (the tunable eps read on the device, no host access) -- replays walk the same
+    trajectory as eager steps, bit for bit."""
+    from vae_training_amd.conv_vae import ConvVAE
+    cfg = CO.ConvConfig(16, (8, 16, 16, 32), 6, -1.5, True)
+    B, lr = 16, 2e-3
+    p, x, z1, z2 = _conv_problem(cfg, B, seed=5)
+    runs = []
+    for graph in (False, True):
+        net = ConvVAE(B, 16, (8, 16, 16, 32), 6, -1.5, True)
+        params, grads, m, v = net.new_flat(), net.new_flat(), net.new_flat(), net.new_flat()
+        for name in net.leaves:
+            net.view(params, name).copy_(_dev(p[name]))
+        step = torch.zeros(1, dtype=torch.int32, device="cuda")
+        xs, z1s, z2s = _dev(x), _dev(z1), _dev(z2)
+        losses = []
+        if graph:
+            replay, out4 = net.capture(params, grads, m, v, step, xs, z1s, z2s, lr, warmup=2)
+            losses += [None, None]
+            for _ in range(3):
+                replay()
+                losses.append(float(out4[0]))
+        else:
+            for _ in range(5):
+                losses.append(float(net.train_step(params, grads, m, v, step, xs, z1s, z2s, lr)[0]))
+        runs.append((losses, params.clone(), int(step[0])))
+    (le, pe, se), (lg, pg, sg) = runs
+    assert se == sg == 5 and le[2:] == lg[2:] and torch.equal(pe, pg)
+
+
 def test_conv_vae_train_steps_reduce_the_loss_like_the_oracle():
     from oracle import elbo_oracle as O
     from vae_training_amd.conv_vae import ConvVAE

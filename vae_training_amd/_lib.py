@@ -46,6 +46,7 @@ SIGNATURES = {
     "vaek_dense_bwd_dx": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vaek_dense_bwd_dw": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "vaek_elbo_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
+    "vaek_elbo_fwd_bwd_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
     "vaek_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _i32, _vp, _f32, _vp]),
     "vaek_train_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp]),
     "vaek_train_step_grads_only": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -12,8 +12,8 @@ A train step is assembled here from the library's blocks (include/vaek.h), every
             gradient, the relu of the layer below applied as a mask)
   update    vaek_adam_step over the flat parameter vector
 Parameters, gradients and Adam moments are ONE flat float32 buffer each, in the leaf order of ConvVAE.leaves() (the oracle's);
-PyTorch holds the device memory and slices views -- it computes nothing.  This is a first, launch-per-layer assembly (about 40
-launches per step, and one host read of the epsilon parameter per step).  Tensors that a bf16-operand kernel reads again travel
+PyTorch holds the device memory and slices views -- it computes nothing.  This is a launch-per-layer assembly (about 95
+launches per step, none of which touches the host: capture() turns the step into a hipGraph).  Tensors that a bf16-operand kernel reads again travel
 with a bf16 copy written by the epilogue that produced them (conv.py: x16 / want16), so nothing is converted twice."""
 import math
 
@@ -91,8 +91,8 @@ class ConvVAE:
             y, y16 = _pair(conv2d_transpose_forward(dec[-1], P(f"Decoder/ConvT{i}/kernel"), P(f"Decoder/ConvT{i}/bias"), relu=i < 3,
                                                     y16=dec16[-1], want16=i < 2))
             dec.append(y); dec16.append(y16)
-        eps = float(P("epsilon")[0]) * self.eps_cli if self.tdv else self.eps_cli        # one host read per step (see the module text)
-        out4, d, _ = e.elbo_fwd_bwd(x.view(B, S * S), dec[4].view(B, S * S), None, z2.view(B, S * S), mu, lv, eps)
+        out4, d, _ = e.elbo_fwd_bwd(x.view(B, S * S), dec[4].view(B, S * S), None, z2.view(B, S * S), mu, lv, self.eps_cli,
+                                    eps_param=P("epsilon") if self.tdv else None)        # the tunable eps is read on the device
         # ---- backward: decoder
         d, d16 = d.view(B, S, S, 1), None
         for i in reversed(range(4)):
@@ -124,3 +124,18 @@ class ConvVAE:
         step_dev += 1
         self.eng.adam_step(params, grads, m, v, lr, step_dev=step_dev)
         return out4
+
+    def capture(self, params, grads, m, v, step_dev, x, z1, z2, lr, warmup=2):
+        """The train step as a hipGraph over these buffers (nothing in it touches the host): returns (replay, out4) -- replay() runs one
+        step on the CURRENT contents of params / m / v / step_dev / x / z1 / z2, out4 is rewritten by every replay.  The `warmup` eager
+        steps it runs first (per-kernel attributes are set on first use) DO update the parameters."""
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.train_step(params, grads, m, v, step_dev, x, z1, z2, lr)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out4 = self.train_step(params, grads, m, v, step_dev, x, z1, z2, lr)
+        return graph.replay, out4

@@ -591,10 +591,10 @@ int vaek_dense_bwd_dw(vaek_ctx* ctx, const float* x, const float* dy, float* dwb
     return launch_sum_slabs(slabs, n, S, dwb, n, (hipStream_t)stream);
 }
 
-int vaek_elbo_fwd_bwd(vaek_ctx* ctx, const float* x, const float* x_hat_lin, const float* x_hat_sig, const float* z2,
-                      const float* mu, const float* logvar_e, float eps, float* d_lin, float* d_sig, float* out4,
-                      int32_t rows, int32_t data_dim, int32_t latent_dim, int64_t batch_total, void* workspace,
-                      void* stream) {
+static int elbo_fwd_bwd_impl(vaek_ctx* ctx, const float* x, const float* x_hat_lin, const float* x_hat_sig, const float* z2,
+                             const float* mu, const float* logvar_e, const float* eps_param, float eps, float* d_lin, float* d_sig, float* out4,
+                             int32_t rows, int32_t data_dim, int32_t latent_dim, int64_t batch_total, void* workspace,
+                             void* stream) {
     if (!ctx || !x || !x_hat_lin || !z2 || !mu || !logvar_e || !out4 || rows <= 0 || data_dim <= 0 || latent_dim <= 0 ||
         (d_lin && x_hat_sig && !d_sig)) {
         set_error("vaek_elbo_fwd_bwd: invalid argument");
@@ -610,13 +610,30 @@ int vaek_elbo_fwd_bwd(vaek_ctx* ctx, const float* x, const float* x_hat_lin, con
     const int64_t bt = batch_total > 0 ? batch_total : rows;
     ElboArgs e{};
     e.x = x; e.y_lin = x_hat_lin; e.y_sig = x_hat_sig; e.z2 = z2; e.mu = mu;
-    e.eps_param = nullptr; e.eps_cli = eps; e.d_lin = d_lin; e.d_sig = d_sig;
+    e.eps_param = eps_param; e.eps_cli = eps; e.d_lin = d_lin; e.d_sig = d_sig;
     e.partial = at<float>(workspace, ctx->ws_epart_blk);
     e.rows = rows; e.D = data_dim; e.L = latent_dim; e.S = Se; e.rows_per_split = rpe;
     e.inv_bt = (float)(1.0 / (double)bt); e.step_dev = nullptr;
     if ((rc = launch_elbo(e, (hipStream_t)stream))) return rc;
-    return launch_elbo_out4(e.partial, Se, logvar_e, latent_dim, data_dim, eps, (float)rows, e.inv_bt, out4,
+    return launch_elbo_out4(e.partial, Se, logvar_e, latent_dim, data_dim, eps_param, eps, (float)rows, e.inv_bt, out4,
                             (hipStream_t)stream);
+}
+
+int vaek_elbo_fwd_bwd(vaek_ctx* ctx, const float* x, const float* x_hat_lin, const float* x_hat_sig, const float* z2,
+                      const float* mu, const float* logvar_e, float eps, float* d_lin, float* d_sig, float* out4,
+                      int32_t rows, int32_t data_dim, int32_t latent_dim, int64_t batch_total, void* workspace,
+                      void* stream) {
+    return elbo_fwd_bwd_impl(ctx, x, x_hat_lin, x_hat_sig, z2, mu, logvar_e, nullptr, eps, d_lin, d_sig, out4, rows, data_dim, latent_dim,
+                             batch_total, workspace, stream);
+}
+
+int vaek_elbo_fwd_bwd_dev(vaek_ctx* ctx, const float* x, const float* x_hat_lin, const float* x_hat_sig, const float* z2,
+                          const float* mu, const float* logvar_e, const float* eps_param_dev, float eps_scale, float* d_lin, float* d_sig,
+                          float* out4, int32_t rows, int32_t data_dim, int32_t latent_dim, int64_t batch_total, void* workspace,
+                          void* stream) {
+    if (!eps_param_dev) { set_error("vaek_elbo_fwd_bwd_dev: invalid argument"); return VAEK_ERR_INVALID; }
+    return elbo_fwd_bwd_impl(ctx, x, x_hat_lin, x_hat_sig, z2, mu, logvar_e, eps_param_dev, eps_scale, d_lin, d_sig, out4, rows, data_dim,
+                             latent_dim, batch_total, workspace, stream);
 }
 
 int vaek_adam_step(vaek_ctx* ctx, float* params, const float* grads, float* m, float* v, int64_t n, float lr,

@@ -440,11 +440,11 @@ __global__ __launch_bounds__(64) void out4_kernel(const float* partial, int S, c
     out4[3] = want_deps ? (sdeps + 0.5f * rows * (float)D) * inv_bt : eps;
 }
 
-int launch_elbo_out4(const float* partial, int S, const float* lv, int L, int D,
+int launch_elbo_out4(const float* partial, int S, const float* lv, int L, int D, const float* eps_param,
                      float eps, float rows, float inv_bt, float* out4, hipStream_t st) {
     ProfScope ps("out4", st);
     launch_k(ps, out4_kernel, dim3(1), dim3(64), 0, st, partial, S, lv,
-                       (const float*)nullptr, eps, L, D, rows, inv_bt, out4, 1);
+                       eps_param, eps, L, D, rows, inv_bt, out4, 1);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
 }

@@ -225,8 +225,8 @@ int launch_adam(float* params, const float* grads, float* m, float* v, int64_t n
 int launch_add_noise(const float* y_lin, const float* y_sig, const float* z2, const float* eps_param,
                      float eps_cli, float* x_hat, int64_t n, hipStream_t st);
 // stand-alone ELBO finalisation for vaek_elbo_fwd_bwd: out4 = {loss, dkl, mse, d eps}
-int launch_elbo_out4(const float* partial, int S, const float* lv, int L, int D,
-                     float eps, float rows, float inv_bt, float* out4, hipStream_t st);
+int launch_elbo_out4(const float* partial, int S, const float* lv, int L, int D, const float* eps_param,
+                     float eps, float rows, float inv_bt, float* out4, hipStream_t st);   // eps = eps_param ? eps_param[0] * eps : eps
 // eval: out4 = {loss, dkl, mse, eps} from slabs
 int launch_eval_out4(const float* partial, int S, const float* params, int64_t off_epsp,
                      int64_t off_eps, int L, int D, float eps_cli, float rows, float inv_bt, float* out4,

@@ -322,15 +322,21 @@ class Engine:
                                               _ptr(self.workspace), _stream()))
         return dwb
 
-    def elbo_fwd_bwd(self, x, x_hat_lin, x_hat_sig, z2, mu, logvar_e, eps, batch_total=0, grads=True):
+    def elbo_fwd_bwd(self, x, x_hat_lin, x_hat_sig, z2, mu, logvar_e, eps, batch_total=0, grads=True, eps_param=None):
+        """eps_param (a one-element device tensor): eps = eps_param[0] * eps, read on the device (vaek_elbo_fwd_bwd_dev)."""
         rows, D = x.shape
         L = mu.shape[1]
         out4 = torch.empty(4, dtype=torch.float32, device=self.device)
         d_lin = torch.empty_like(x_hat_lin) if grads else None
         d_sig = torch.empty_like(x_hat_sig) if (grads and x_hat_sig is not None) else None
-        _lib.check(self.lib.vaek_elbo_fwd_bwd(self.h, _ptr(x), _ptr(x_hat_lin), _ptr(x_hat_sig), _ptr(z2), _ptr(mu),
-                                              _ptr(logvar_e), float(eps), _ptr(d_lin), _ptr(d_sig), _ptr(out4),
-                                              rows, D, L, int(batch_total), _ptr(self.workspace), _stream()))
+        if eps_param is not None:
+            _lib.check(self.lib.vaek_elbo_fwd_bwd_dev(self.h, _ptr(x), _ptr(x_hat_lin), _ptr(x_hat_sig), _ptr(z2), _ptr(mu),
+                                                      _ptr(logvar_e), _ptr(eps_param), float(eps), _ptr(d_lin), _ptr(d_sig), _ptr(out4),
+                                                      rows, D, L, int(batch_total), _ptr(self.workspace), _stream()))
+        else:
+            _lib.check(self.lib.vaek_elbo_fwd_bwd(self.h, _ptr(x), _ptr(x_hat_lin), _ptr(x_hat_sig), _ptr(z2), _ptr(mu),
+                                                  _ptr(logvar_e), float(eps), _ptr(d_lin), _ptr(d_sig), _ptr(out4),
+                                                  rows, D, L, int(batch_total), _ptr(self.workspace), _stream()))
         return out4, d_lin, d_sig
 
     def adam_step(self, params, grads, m, v, lr, step=None, step_dev=None, grad_scale=1.0):
