@@ -456,7 +456,8 @@ struct HsDwArgs {
 // LDS image of a BK-row(k) x 128-feature tile: 256-byte rows, 16-byte chunk ch of row k at chunk position
 // ch ^ (((k & 3) << 2) | ((k >> 2) & 3)): the 32 lanes of a ds_read_b64_tr_b16 half (4 k-rows x 2 blocks of 16
 // features) then cover the 256-byte bank row exactly.
-template <int BK, int NS, bool CONV = false>
+// NARROW (N <= 64): the four waves stack along M (32 rows x 64 columns each) instead of 2 x 2 -- no wave multiplies columns past N
+template <int BK, int NS, bool CONV = false, bool NARROW = false>
 __global__ __launch_bounds__(256) void hs_tn_kernel(const HsDwArgs g) {
     constexpr int BM = 128, BN = 128, T_BYTES = BK * 256, BUF = 2 * T_BYTES;
     constexpr int PASSES = BK / 16, P = 2 * PASSES;           // staging passes per operand tile; loads per k-tile and wave
@@ -470,7 +471,8 @@ __global__ __launch_bounds__(256) void hs_tn_kernel(const HsDwArgs g) {
     const int kbeg = split * g.rows_per_split, kend = min(g.rows, kbeg + g.rows_per_split);
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wv >> 1, wn = wv & 1;
+    constexpr int TI = NARROW ? 1 : 2, WROWS = NARROW ? 32 : 64;      // m-fragments per wave, rows of M per wave
+    const int wm = NARROW ? wv : wv >> 1, wn = NARROW ? 0 : wv & 1;
 
     // staging: 16 BK chunks per tile; position p -> k-row p >> 4, chunk slot p & 15
     int a_col[PASSES], b_col[PASSES], s_row[PASSES];
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(256) void hs_tn_kernel(const HsDwArgs g) {
         const int krow = 8 * h + 4 * u + q, xr = (q << 2) | ((2 * h + u) & 3);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int mcol = wm * 64 + i * 32 + 16 * g16 + 4 * p;
+            const int mcol = wm * WROWS + (i % TI) * 32 + 16 * g16 + 4 * p;
             a_addr[i][u] = krow * 256 + (((mcol >> 3) ^ xr) << 4) + ((mcol >> 2) & 1) * 8;
             const int ncol = wn * 64 + i * 32 + 16 * g16 + 4 * p;
             b_addr[i][u] = krow * 256 + (((ncol >> 3) ^ xr) << 4) + ((ncol >> 2) & 1) * 8 + T_BYTES;
@@ -553,16 +555,18 @@ __global__ __launch_bounds__(256) void hs_tn_kernel(const HsDwArgs g) {
         }
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
-            bf16x8 fa[2], fb[2];
+            bf16x8 fa[TI], fb[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const bf16x4 a0 = tr_read(boff + a_addr[i][0] + s * 4096), a1 = tr_read(boff + a_addr[i][1] + s * 4096);
+                if (i < TI) {
+                    const bf16x4 a0 = tr_read(boff + a_addr[i][0] + s * 4096), a1 = tr_read(boff + a_addr[i][1] + s * 4096);
+                    fa[i % TI] = bf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                }
                 const bf16x4 b0 = tr_read(boff + b_addr[i][0] + s * 4096), b1 = tr_read(boff + b_addr[i][1] + s * 4096);
-                fa[i] = bf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                 fb[i] = bf16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             if (do_bias) {
@@ -580,10 +584,10 @@ __global__ __launch_bounds__(256) void hs_tn_kernel(const HsDwArgs g) {
         const int n = n0 + wn * 64 + j * 32 + (lane & 31);
         if (n >= g.N) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int m = m0 + wm * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (m < g.M) C[(long long)m * g.N + n] = acc[i][j][r];
             }
         if (do_bias && h == 0) C[(long long)g.M * g.N + n] = accb[j][0];      // every row of 1 . dY is the column sum
@@ -924,10 +928,11 @@ int launch_hs_conv_dw(const __bf16* x, const __bf16* dy, const __bf16* zeros, fl
     g.rows_per_split = rows_per_split; g.slab_stride = slab_stride;
     g.tiles_m = (g.M + 127) / 128; g.tiles_n = (g.N + 127) / 128;
     g.H = H; g.W = W; g.Cin = Cin; g.sh_hw = 31 - __builtin_clz(hw); g.sh_w = 31 - __builtin_clz(Wo); g.zeros = zeros;
-    const auto fn = hs_tn_kernel<64, 2, true>;
+    const bool narrow = Cout <= 64;
+    const auto fn = narrow ? hs_tn_kernel<64, 2, true, true> : hs_tn_kernel<64, 2, true>;
     const size_t lds = 2 * 2 * 64 * 256;
-    static thread_local bool attr_set = false;
-    if (!attr_set) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+    static thread_local bool attr_set[2] = {false, false};
+    if (!attr_set[narrow]) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set[narrow] = true; }
     ProfScope ps("conv_wgrad_bf16s", st);
     launch_k(ps, fn, dim3((unsigned)(g.tiles_m * g.tiles_n * S)), dim3(256), lds, st, g);
     VAEK_HIP_CHECK(hipGetLastError());
