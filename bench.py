@@ -216,16 +216,27 @@ def cpu_baseline_c1(seconds_each=1.5):
 
 def bench_conv(args):
     """Workload C5 (BASELINE config 5; no reference counterpart): the convolutional VAE's train step assembled from the
-    library's blocks (vae_training_amd/conv_vae.py), one GPU, the step captured into a hipGraph.  Its own line: same metric and unit."""
+    library's blocks (vae_training_amd/conv_vae.py).  One GPU: the step captured into a hipGraph.  N GPUs (torch.distributed.run):
+    data parallel, weak scaling -- every rank its own batch, one RCCL all-reduce of the flat gradient per step, eager.  Its own
+    line: same metric and unit."""
     import torch
 
     from vae_training_amd.conv_vae import ConvVAE
-    if int(os.environ.get("WORLD_SIZE", "1")) != 1:
-        sys.exit("bench.py --workload C5: single GPU only so far")
+    from vae_training_amd.parallel import GradExchange
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local_rank = 0 if args.rehearse_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     S, widths, L = 64, (32, 64, 128, 256), 32
     B = args.batch or 4096                                   # config 5 names 32 768 over 8 GPUs
     steps, warm = min(args.steps, 20), min(max(args.warmup, 2), 5)
-    net = ConvVAE(B, S, widths, L, -3.0, True)
+    net = ConvVAE(B, S, widths, L, -3.0, True, device=local_rank, world=world)
     g = torch.Generator(device="cpu").manual_seed(0)
     params, grads, m, v = net.new_flat(), net.new_flat(), net.new_flat(), net.new_flat()
     for name, (off, shape) in net.leaves.items():
@@ -234,37 +245,61 @@ def bench_conv(args):
             net.view(params, name).copy_((torch.randn(*shape, generator=g) / math.sqrt(fan)).to(net.device))
         elif name == "epsilon":
             net.view(params, name).fill_(1.0)
+    g = torch.Generator(device="cpu").manual_seed(1 + rank)  # every rank its own shard of the global batch
     x = torch.rand(B, S, S, 1, generator=g).to(net.device)
     z1 = torch.randn(B, L, generator=g).to(net.device)
     z2 = torch.randn(B, S, S, 1, generator=g).to(net.device)
     step = torch.zeros(1, dtype=torch.int32, device=net.device)
-    # the step as one hipGraph (nothing in it touches the host): ~95 launches whose 4-6 us gaps are 8 % of an eager step
-    replay, out4 = net.capture(params, grads, m, v, step, x, z1, z2, 1e-4, warmup=warm)
-    replay()
+    if world == 1:
+        # the step as one hipGraph (nothing in it touches the host): ~95 launches whose 4-6 us gaps are 8 % of an eager step
+        run, out4 = net.capture(params, grads, m, v, step, x, z1, z2, 1e-4, warmup=warm)
+        run()
+    else:
+        exch = GradExchange(net.eng, dist, mode="rccl")
+        box = {}
+
+        def run():
+            box["out4"] = net.train_step(params, grads, m, v, step, x, z1, z2, 1e-4, all_reduce=exch.all_reduce)
+        for _ in range(warm):
+            run()
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        replay()
+        run()
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     elapsed = time.perf_counter() - t0
-    rep = None                                               # (the library's per-launch profiler records eager launches only)
+    if world > 1:
+        out4 = box["out4"]
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)             # the slowest rank's clock
+        elapsed = float(t[0])
+        chk = torch.stack([params.double().sum(), params.double().abs().sum()]).cpu()
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi), "replicas diverged"
     loss = float(out4[0])
     assert math.isfinite(loss)
+    if rank != 0:
+        return
     chans = [1, *widths]
     macs = sum((S >> (i + 1)) ** 2 * chans[i + 1] * 16 * chans[i] for i in range(4))       # one conv stack, forward, per sample
     flops = 3 * 2 * (2 * macs + 2 * net.bott * L)                                           # both stacks + the two Dense; fwd + 2 x bwd
-    kernels_s = sum(r["total_ms"] for r in rep.values()) / steps * 1e-3 if rep else None
-    out = {"metric": "ELBO train-step samples/sec", "value": B * steps / elapsed, "unit": "samples/s", "n_gpus": 1, "steps": steps,
+    tf = world * B * flops / (elapsed / steps) / 1e12
+    out = {"metric": "ELBO train-step samples/sec", "value": world * B * steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": steps,
            "warmup": warm, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "bf16", "data": "synthetic",
            "config": {"workload": "C5: conv VAE 64x64x1, 4x4/s2 convs 32|64|128|256, L=32 (BASELINE config 5; no reference counterpart)",
-                      "batch_per_gpu": B, "params": net.n_params, "path": "blocks, launch per layer, one hipGraph per step", "final_loss": loss},
-           "roofline": {"bound": "mfma", "achieved": B * flops / (kernels_s or elapsed / steps) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
-                        "frac": B * flops / (kernels_s or elapsed / steps) / 1e12 / 2500.0, "traffic": None,
-                        "kernel": "all launches of a step", "kernel_avg_us": (kernels_s or 0.0) * 1e6,
-                        "algorithmic_per_launch": B * flops,
-                        "step_level": {"achieved": B * flops / (elapsed / steps) / 1e12, "frac": B * flops / (elapsed / steps) / 1e12 / 2500.0},
-                        "step_kernels_us": {k: r["total_ms"] / steps * 1e3 for k, r in (rep or {}).items()}},
+                      "batch_per_gpu": B, "global_batch": B * world, "params": net.n_params, "parallelism": f"dp{world}",
+                      "path": "blocks, launch per layer, one hipGraph per step" if world == 1 else
+                              "blocks, launch per layer, eager + one all-reduce of the flat gradient per step",
+                      "grad_exchange": "none" if world == 1 else "rccl", "final_loss": loss},
+           "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0 * world, "unit": "TFLOP/s", "frac": tf / (2500.0 * world), "traffic": None,
+                        "kernel": "all launches of a step", "kernel_avg_us": 0.0, "algorithmic_per_launch": world * B * flops,
+                        "step_level": {"achieved": tf, "frac": tf / (2500.0 * world)}, "step_kernels_us": {}},
            "cpu_baseline": None}
     print(json.dumps(out), flush=True)
 
@@ -274,7 +309,7 @@ def main():
         ap = argparse.ArgumentParser()
         ap.add_argument("--workload"); ap.add_argument("--gpus", type=int, default=1); ap.add_argument("--steps", type=int, default=10)
         ap.add_argument("--warmup", type=int, default=3); ap.add_argument("--batch", type=int, default=0)
-        ap.add_argument("--no-cpu-baseline", action="store_true")
+        ap.add_argument("--no-cpu-baseline", action="store_true"); ap.add_argument("--rehearse-one-gpu", action="store_true")
         return bench_conv(ap.parse_args())
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)

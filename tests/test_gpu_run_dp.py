@@ -81,3 +81,37 @@ def test_bench_py_two_ranks_rehearsed_on_one_gpu(comm, port):
     # P2P transport: the moments are exchanged inside the persistent launch; RCCL transport: the per-sample step + all-reduce
     assert out["config"]["step_entry_point"].startswith("vaek_train_steps" if comm == "p2p" else "vaek_train_step")
     assert (comm == "p2p") == ("persistent" in out["config"]["step_entry_point"])
+
+
+def test_conv_vae_two_ranks_equal_one_rank_on_the_whole_batch(tmp_path):
+    """The convolutional VAE data parallel (conv_vae.py: world > 1): the all-reduced shard gradients are the whole batch's gradient,
+    the replicas stay bitwise identical over 4 steps (tests/dp_conv_worker.py)."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29523", os.path.join(ROOT, "tests", "dp_conv_worker.py")]
+    r = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    res = {}
+    for ln in r.stdout.splitlines():
+        if ln.startswith("RESULT"):
+            kv = dict(t.split("=") for t in ln.split()[1:])
+            res[int(kv["rank"])] = kv
+    assert set(res) == {0, 1}, r.stdout[-1500:]
+    assert all(kv["replicas_identical"] == "True" and kv["steps"] == "4" for kv in res.values()), res
+    assert float(res[0]["worst_rel"]) <= 1e-4, res
+
+
+def test_bench_py_conv_two_ranks_rehearsed_on_one_gpu():
+    """bench.py --workload C5 at two ranks on this box's one GPU (gloo standing in for RCCL): one JSON line for n_gpus 2 with the
+    whole-job rate; bench.py itself asserts that the replicas ended identical."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29524", os.path.join(ROOT, "bench.py"), "--workload", "C5", "--gpus", "2", "--rehearse-one-gpu", "--batch", "64",
+           "--steps", "3", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 128 and out["scaling"] == "weak"
+    assert np.isfinite(out["value"]) and out["value"] > 0 and np.isfinite(out["config"]["final_loss"]), out

@@ -31,8 +31,11 @@ def _pair(r):
 
 
 class ConvVAE:
-    def __init__(self, batch, size=64, widths=(32, 64, 128, 256), latent_dim=32, epsilon=-3.0, tunable_decoder_var=True, device=0):
+    def __init__(self, batch, size=64, widths=(32, 64, 128, 256), latent_dim=32, epsilon=-3.0, tunable_decoder_var=True, device=0, world=1):
+        """batch: THIS rank's rows; world > 1: data parallel -- every mean is taken over batch * world rows, so the SUM of the ranks' flat
+        gradients (train_step's `all_reduce`) is the global batch's gradient and every replica applies the same Adam update."""
         assert size % 16 == 0 and len(widths) == 4
+        self.world = int(world)
         self.B, self.S, self.widths, self.L, self.eps_cli, self.tdv = batch, size, tuple(widths), latent_dim, float(epsilon), tunable_decoder_var
         self.bott = (size // 16) ** 2 * widths[3]
         # the block entry points want a context: a linear VAE of the same batch / widest Dense side sizes their workspaces
@@ -91,7 +94,8 @@ class ConvVAE:
             y, y16 = _pair(conv2d_transpose_forward(dec[-1], P(f"Decoder/ConvT{i}/kernel"), P(f"Decoder/ConvT{i}/bias"), relu=i < 3,
                                                     y16=dec16[-1], want16=i < 2))
             dec.append(y); dec16.append(y16)
-        out4, d, _ = e.elbo_fwd_bwd(x.view(B, S * S), dec[4].view(B, S * S), None, z2.view(B, S * S), mu, lv, self.eps_cli,
+        bt = B * self.world                                                                       # the means' denominator: the GLOBAL batch
+        out4, d, _ = e.elbo_fwd_bwd(x.view(B, S * S), dec[4].view(B, S * S), None, z2.view(B, S * S), mu, lv, self.eps_cli, batch_total=bt,
                                     eps_param=P("epsilon") if self.tdv else None)        # the tunable eps is read on the device
         # ---- backward: decoder
         d, d16 = d.view(B, S, S, 1), None
@@ -104,7 +108,7 @@ class ConvVAE:
         dwb = e.dense_bwd_dw(samples, d)                                                          # [kernel | bias] rows
         G("Decoder/FC/kernel").copy_(dwb[:L]); G("Decoder/FC/bias").copy_(dwb[L])
         d_s = e.dense_bwd_dx(d, P("Decoder/FC/kernel"))
-        e.reparam_bwd(d_s, mu, z1, lv, out=G("epsilon_p"))                                        # d_s becomes d_mu in place
+        e.reparam_bwd(d_s, mu, z1, lv, batch_total=bt, out=G("epsilon_p"))                        # d_s becomes d_mu in place
         dwb = e.dense_bwd_dw(flat, d_s)
         G("Encoder/FC/kernel").copy_(dwb[:self.bott]); G("Encoder/FC/bias").copy_(dwb[self.bott])
         d = e.dense_bwd_dx(d_s, P("Encoder/FC/kernel"), flat, relu=True).view(B, S // 16, S // 16, self.widths[3])
@@ -119,8 +123,12 @@ class ConvVAE:
             G("epsilon").copy_(out4[3:4] * self.eps_cli)                                          # eps = param * eps_cli
         return out4
 
-    def train_step(self, params, grads, m, v, step_dev, x, z1, z2, lr):
+    def train_step(self, params, grads, m, v, step_dev, x, z1, z2, lr, all_reduce=None):
+        """all_reduce (world > 1): an in-place SUM over the ranks of a device tensor (parallel.py: GradExchange.all_reduce -- RCCL)."""
         out4 = self.loss_and_grad(params, grads, x, z1, z2)
+        if self.world > 1:
+            all_reduce(grads)
+            all_reduce(out4)                             # {loss, Dkl, mse} partial means -> the global batch's; the d eps slot likewise
         step_dev += 1
         self.eng.adam_step(params, grads, m, v, lr, step_dev=step_dev)
         return out4
@@ -128,7 +136,9 @@ class ConvVAE:
     def capture(self, params, grads, m, v, step_dev, x, z1, z2, lr, warmup=2):
         """The train step as a hipGraph over these buffers (nothing in it touches the host): returns (replay, out4) -- replay() runs one
         step on the CURRENT contents of params / m / v / step_dev / x / z1 / z2, out4 is rewritten by every replay.  The `warmup` eager
-        steps it runs first (per-kernel attributes are set on first use) DO update the parameters."""
+        steps it runs first (per-kernel attributes are set on first use) DO update the parameters.  One GPU only (the data-parallel
+        step runs eagerly around its all-reduce)."""
+        assert self.world == 1
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
