@@ -250,16 +250,16 @@ def bench_conv(args):
     z1 = torch.randn(B, L, generator=g).to(net.device)
     z2 = torch.randn(B, S, S, 1, generator=g).to(net.device)
     step = torch.zeros(1, dtype=torch.int32, device=net.device)
-    if world == 1:
+    if world == 1 and not args.no_graph:
         # the step as one hipGraph (nothing in it touches the host): ~95 launches whose 4-6 us gaps are 8 % of an eager step
         run, out4 = net.capture(params, grads, m, v, step, x, z1, z2, 1e-4, warmup=warm)
         run()
     else:
-        exch = GradExchange(net.eng, dist, mode="rccl")
+        exch = GradExchange(net.eng, dist, mode="rccl") if world > 1 else None
         box = {}
 
         def run():
-            box["out4"] = net.train_step(params, grads, m, v, step, x, z1, z2, 1e-4, all_reduce=exch.all_reduce)
+            box["out4"] = net.train_step(params, grads, m, v, step, x, z1, z2, 1e-4, all_reduce=exch.all_reduce if exch else None)
         for _ in range(warm):
             run()
     torch.cuda.synchronize()
@@ -272,8 +272,9 @@ def bench_conv(args):
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if box_used := (world > 1 or args.no_graph):
         out4 = box["out4"]
+    if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)             # the slowest rank's clock
         elapsed = float(t[0])
@@ -294,7 +295,8 @@ def bench_conv(args):
            "dtype": "bf16", "data": "synthetic",
            "config": {"workload": "C5: conv VAE 64x64x1, 4x4/s2 convs 32|64|128|256, L=32 (BASELINE config 5; no reference counterpart)",
                       "batch_per_gpu": B, "global_batch": B * world, "params": net.n_params, "parallelism": f"dp{world}",
-                      "path": "blocks, launch per layer, one hipGraph per step" if world == 1 else
+                      "path": "blocks, launch per layer, one hipGraph per step" if world == 1 and not args.no_graph else
+                              "blocks, launch per layer, eager" if world == 1 else
                               "blocks, launch per layer, eager + one all-reduce of the flat gradient per step",
                       "grad_exchange": "none" if world == 1 else "rccl", "final_loss": loss},
            "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0 * world, "unit": "TFLOP/s", "frac": tf / (2500.0 * world), "traffic": None,
@@ -310,6 +312,7 @@ def main():
         ap.add_argument("--workload"); ap.add_argument("--gpus", type=int, default=1); ap.add_argument("--steps", type=int, default=10)
         ap.add_argument("--warmup", type=int, default=3); ap.add_argument("--batch", type=int, default=0)
         ap.add_argument("--no-cpu-baseline", action="store_true"); ap.add_argument("--rehearse-one-gpu", action="store_true")
+        ap.add_argument("--no-graph", action="store_true", help="eager launches on one GPU too (counter profiling)")
         return bench_conv(ap.parse_args())
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)

@@ -1,0 +1,35 @@
+# HBM traffic of the convolutional VAE's step per kernel (bench.py --workload C5 --no-graph), from the L2 memory-side counters in
+# separate --pmc passes as tools/pmc_traffic.sh does for the Dense workloads.   bash tools/pmc_traffic_c5.sh
+set -e
+STEPS=2; WARM=2
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_C5_$c -- python3 $R/bench.py --workload C5 --steps $STEPS --warmup $WARM --no-cpu-baseline --no-graph > $R/gpurun_out/pmc_C5_$c.log 2>&1
+done
+cd $R
+python3 - $((STEPS + WARM)) <<'PY'
+import csv, glob, collections, json, sys
+nsteps = int(sys.argv[1])
+tot = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(int)
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(f"gpurun_out/pmc_C5_{c}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == c and "vaek" in r["Kernel_Name"]:
+                name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                tot[name][c] += float(r["Counter_Value"])
+                if c == "FETCH_SIZE":
+                    cnt[name] += 1
+kernels = {}
+for name, v in sorted(tot.items(), key=lambda kv: -(2 * kv[1]["FETCH_SIZE"] + kv[1]["WRITE_SIZE"])):
+    kernels[name] = {"launches_per_step": cnt[name] / nsteps, "read_MB_per_step": round(2 * v["FETCH_SIZE"] * 1024 / nsteps / 1e6, 1),
+                     "write_MB_per_step": round(v["WRITE_SIZE"] * 1024 / nsteps / 1e6, 1)}
+total = sum(k["read_MB_per_step"] + k["write_MB_per_step"] for k in kernels.values())
+out = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_traffic_c5.sh): bench.py --workload C5 --no-graph, "
+               f"{nsteps} eager train steps at B = 4096; gfx950 correction per MI355X_MICROARCH.md: bytes = 2 * FETCH_SIZE * 1024 (read) + WRITE_SIZE * 1024 (write).",
+       "traffic_MB_per_step": round(total, 1), "kernels": kernels}
+json.dump(out, open("gpurun_out/r02_pmc_traffic_C5.json", "w"), indent=1)
+print("total MB per step", round(total, 1))
+for k, v in list(kernels.items())[:14]:
+    print(f"{k[:70]:70s} {v}")
+PY

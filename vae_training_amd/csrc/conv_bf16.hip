@@ -519,7 +519,9 @@ __global__ __launch_bounds__(256) void thin_conv_t_fwd_kernel(const ThinArgs g, 
 // pixel meet by a butterfly, lane 0 stores the four values.
 __global__ __launch_bounds__(256) void thin_conv_t_fwd4_kernel(const ThinArgs g, const int relu) {
     const int C = g.C, LP = C / 4;
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x, groups = (long long)gridDim.x * 256 / LP;
+    unsigned lb = blockIdx.x;                            // XCD-aware: each XCD (own L2) walks a contiguous pixel range -- the 3 x 3
+    if (gridDim.x % 8 == 0) lb = (lb % 8) * (gridDim.x / 8) + lb / 8;      // neighbourhoods then re-read from L2, not 3x from HBM (PMC)
+    const long long gid = (long long)lb * 256 + threadIdx.x, groups = (long long)gridDim.x * 256 / LP;
     const int lg = (int)(gid % LP);
     float4 kk[16];
 #pragma unroll

@@ -618,7 +618,12 @@ __global__ __launch_bounds__(64 * WM * WN) void hs_conv_kernel(const HsConvArgs 
     static_assert(BM * CPR % NTH == 0 && BN * CPR % NTH == 0 && B_PASSES >= 1, "whole staging passes");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // T: the four parity classes of a tile are neighbours in the launch order -- they read the same input pixels (one HBM read, three L2 hits)
-    const unsigned tiles_n = g.N / BN, bid = MODE == HC_T ? blockIdx.x >> 2 : blockIdx.x, cls = MODE == HC_T ? blockIdx.x & 3 : 0;
+    // XCD-aware order (workgroups are dealt round-robin over the 8 XCDs, each with its own L2): every XCD gets a contiguous run of
+    // the tile space, so the four classes / the column tiles of one row tile, and the row tiles that share window rows, meet in ONE L2
+    // (PMC: the 32-column transposed layers read their input 4x from HBM when the classes were merely adjacent in launch order)
+    unsigned lid = blockIdx.x;
+    if (gridDim.x % 8 == 0) lid = (lid % 8) * (gridDim.x / 8) + lid / 8;
+    const unsigned tiles_n = g.N / BN, bid = MODE == HC_T ? lid >> 2 : lid, cls = MODE == HC_T ? lid & 3 : 0;
     const int m0 = (int)(bid / tiles_n) * BM, n0 = (int)(bid % tiles_n) * BN;
     const int pp = (int)(cls >> 1), qq = (int)(cls & 1);
     const int t = threadIdx.x, lane = t & 63;
