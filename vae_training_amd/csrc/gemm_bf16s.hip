@@ -608,9 +608,9 @@ struct HsConvArgs {
     int relu, H, W, Cin, Cout, M, N, K;       // H, W: the INPUT tensor's spatial size
     int sh_c, hw, wo;                         // log2 C_in; GEMM rows per image and per image row (FWD: Ho Wo, Wo; T: H W, W)
 };
-template <int MODE, int BN, int WM, int WN, int BK, int NS>
+template <int MODE, int BN, int WM, int WN, int BK, int NS, int BM = 128>
 __global__ __launch_bounds__(64 * WM * WN) void hs_conv_kernel(const HsConvArgs g) {
-    constexpr int BM = 128, NTH = 64 * WM * WN;
+    constexpr int NTH = 64 * WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RB = 2 * BK, CPR = BK / 8;
     constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, BUF = A_BYTES + B_BYTES;
@@ -945,14 +945,14 @@ int launch_hs_conv_dw(const __bf16* x, const __bf16* dy, const __bf16* zeros, fl
 }
 
 // the convolution's forward (mode 0) / transposed forward (mode 1) on bf16 copies; shapes checked by the caller (conv_bf16.hip)
-template <int MODE, int BN, int WM, int WN, int BK, int NS>
+template <int MODE, int BN, int WM, int WN, int BK, int NS, int BM = 128>
 static int hs_conv_launch(const HsConvArgs& g, hipStream_t st) {
-    const auto fn = hs_conv_kernel<MODE, BN, WM, WN, BK, NS>;
-    constexpr size_t lds = (size_t)NS * (128 + BN) * 2 * BK;
+    const auto fn = hs_conv_kernel<MODE, BN, WM, WN, BK, NS, BM>;
+    constexpr size_t lds = (size_t)NS * (BM + BN) * 2 * BK;
     static thread_local bool attr_set = false;
     if (!attr_set) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
     ProfScope ps(MODE == HC_FWD ? "conv_fwd_bf16s" : "conv_t_fwd_bf16s", st);
-    launch_k(ps, fn, dim3((unsigned)(((g.M + 127) / 128) * (g.N / BN)) * (MODE == HC_T ? 4u : 1u)), dim3(64 * WM * WN), lds, st, g);
+    launch_k(ps, fn, dim3((unsigned)(((g.M + BM - 1) / BM) * (g.N / BN)) * (MODE == HC_T ? 4u : 1u)), dim3(64 * WM * WN), lds, st, g);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
 }
@@ -972,11 +972,11 @@ int launch_hs_conv(int mode, const __bf16* x, const __bf16* wb, const __bf16* ze
     if (mode == HC_FWD) {
         if (Cout % 128 == 0) return hs_conv_launch<HC_FWD, 128, 2, 2, 64, 2>(g, st);
         if (Cout % 64 == 0) return hs_conv_launch<HC_FWD, 64, 2, 2, 64, 3>(g, st);
-        return hs_conv_launch<HC_FWD, 32, 4, 1, 64, 3>(g, st);
+        return hs_conv_launch<HC_FWD, 32, 4, 1, 64, 2, 256>(g, st);     // short reductions, thin tiles: 256 rows per workgroup halve the per-tile latencies
     }
     if (Cout % 128 == 0) return hs_conv_launch<HC_T, 128, 2, 2, 64, 2>(g, st);
     if (Cout % 64 == 0) return hs_conv_launch<HC_T, 64, 2, 2, 64, 3>(g, st);
-    return hs_conv_launch<HC_T, 32, 4, 1, 64, 3>(g, st);
+    return hs_conv_launch<HC_T, 32, 4, 1, 64, 2, 256>(g, st);
 }
 int launch_cvt_bf16_t(const float* src, __bf16* dst, int K, int N, __bf16* zero8, hipStream_t st) {
     ProfScope ps("cvt_bf16_t", st);
