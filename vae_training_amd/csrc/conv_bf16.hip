@@ -799,6 +799,21 @@ __global__ __launch_bounds__(256) void thin_conv_fwd_mfma_kernel(const ThinArgs 
     }
 }
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// the gathering loaders' 16 bytes of zeros (taps outside the image): a module-scope device array, zero from load time on -- nothing to
+// launch per call
+__device__ __attribute__((aligned(256))) __bf16 g_conv_zero_page[128];
+static const __bf16* conv_zero_page() {
+    static thread_local const __bf16* p = nullptr;
+    static thread_local int dev_of_p = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (!p || dev != dev_of_p) {
+        void* q = nullptr;
+        if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_conv_zero_page)) != hipSuccess) return nullptr;
+        p = static_cast<const __bf16*>(q); dev_of_p = dev;
+    }
+    return p;
+}
 static bool thin_channels_ok(int c) { return c >= 1 && c <= 256 && 256 % c == 0; }
 static bool thin_groups_ok(int c) { return c % 8 == 0 && c <= 256 && 256 % c == 0; }     // c / 8 divides 32: lanes of a group stay in a wave
 constexpr int kThinWgradBlocks = 2048;
@@ -809,7 +824,7 @@ using namespace vaek;
 
 // The fast form (channel counts multiples of 8, power-of-two output sizes): bf16 copies of the two tensors, then the bf16-storage dW
 // kernel of gemm_bf16s.hip with its loader gathering the (kh, kw, c) columns from the image (LDS-DMA, transposed LDS reads, a
-// ring of k-tiles): 2.2 ms -> 0.4 ms per call at config 5's layer shapes.  Workspace: [256 B zeros | x bf16 | dy bf16 | slabs].
+// ring of k-tiles): 2.2 ms -> 0.4 ms per call at config 5's layer shapes.  Workspace: [256 B unused | x bf16 | dy bf16 | slabs].
 struct ConvWFast { bool ok; int S, rps; size_t off_x, off_dy, off_slab, bytes; };
 static ConvWFast conv_wgrad_fast(long long batch, int H, int W, int Cin, int Cout) {
     ConvWFast f{};
@@ -830,7 +845,7 @@ static ConvWFast conv_wgrad_fast(long long batch, int H, int W, int Cin, int Cou
 
 // The fast form of the forward / transposed forward (C_in a power of two >= 8 / 16, C_out a multiple of 32, a workspace given):
 // bf16 copies of the tensor and the kernel, then gemm_bf16s.hip's LDS-DMA GEMM with the gather in its loader (hs_conv_kernel).
-// Workspace: [256 B zeros | x bf16 | kernel bf16].
+// Workspace: [256 B unused | x bf16 | kernel bf16].
 struct ConvFFast { bool ok; size_t off_x, off_w, bytes; };
 static ConvFFast conv_fwd_fast(int mode, long long batch, int H, int W, int Cin, int Cout) {
     ConvFFast f{};
@@ -850,7 +865,8 @@ extern "C" int vaek_conv2d_forward_workspace(int32_t batch, int32_t height, int3
 static int conv_forward_fast(int mode, const ConvFFast& f, const float* x, const float* w, const float* bias, const float* mask, float* out,
                              void* workspace, const void* x16, void* out16, int batch, int H, int W, int Cin, int Cout, bool relu, hipStream_t st) {
     char* ws = static_cast<char*>(workspace);
-    __bf16* zeros = reinterpret_cast<__bf16*>(ws);
+    const __bf16* zeros = conv_zero_page();
+    if (!zeros) { set_error("convolution: no page of zeros (hipGetSymbolAddress)"); return VAEK_ERR_HIP; }
     const __bf16* xb = static_cast<const __bf16*>(x16);
     __bf16* wb = reinterpret_cast<__bf16*>(ws + f.off_w);
     int rc = VAEK_OK;
@@ -859,7 +875,7 @@ static int conv_forward_fast(int mode, const ConvFFast& f, const float* x, const
         rc = launch_cvt_bf16(x, mine, (int64_t)batch * H * W * Cin, nullptr, st);
         xb = mine;
     }
-    if (rc == VAEK_OK) rc = mode == 0 ? launch_cvt_bf16_t(w, wb, 16 * Cin, Cout, zeros, st) : launch_cvt_bf16(w, wb, (int64_t)16 * Cin * Cout, zeros, st);
+    if (rc == VAEK_OK) rc = mode == 0 ? launch_cvt_bf16_t(w, wb, 16 * Cin, Cout, nullptr, st) : launch_cvt_bf16(w, wb, (int64_t)16 * Cin * Cout, nullptr, st);
     if (rc == VAEK_OK) rc = launch_hs_conv(mode, xb, wb, zeros, bias, mask, out, static_cast<__bf16*>(out16), batch, H, W, Cin, Cout, relu, st);
     return rc;
 }
@@ -912,7 +928,8 @@ extern "C" int vaek_conv2d_weight_grad(const float* x, const float* dy, float* d
     const ConvWFast f = conv_wgrad_fast(batch, height, width, c_in, c_out);
     if (f.ok) {
         char* ws = static_cast<char*>(workspace);
-        __bf16* zeros = reinterpret_cast<__bf16*>(ws);
+        const __bf16* zeros = conv_zero_page();
+        if (!zeros) { set_error("convolution: no page of zeros (hipGetSymbolAddress)"); return VAEK_ERR_HIP; }
         const __bf16* xb = static_cast<const __bf16*>(x_bf16);
         const __bf16* dyb = static_cast<const __bf16*>(dy_bf16);
         float* slab = reinterpret_cast<float*>(ws + f.off_slab);
@@ -928,10 +945,11 @@ extern "C" int vaek_conv2d_weight_grad(const float* x, const float* dy, float* d
             rc = launch_cvt_bf16(dy, mine, (int64_t)pixels * c_out, nullptr, st0);
             dyb = mine;
         }
-        if (rc == VAEK_OK) rc = launch_cvt_bf16(nullptr, nullptr, 0, zeros, st0);           // the loader's page of zeros
         if (rc == VAEK_OK) rc = launch_hs_conv_dw(xb, dyb, zeros, slab, slab_stride, f.S, f.rps, batch, height, width, c_in, c_out, st0);
-        if (rc == VAEK_OK) rc = launch_sum_slabs(slab, slab_stride, f.S, dw, (int64_t)16 * c_in * c_out, st0);
-        if (rc == VAEK_OK && dbias) rc = launch_sum_slabs(slab + (long long)16 * c_in * c_out, slab_stride, f.S, dbias, c_out, st0);
+        const int64_t nk = (int64_t)16 * c_in * c_out;
+        if (rc == VAEK_OK && dbias == dw + nk) return launch_sum_slabs(slab, slab_stride, f.S, dw, nk + c_out, st0);     // [kernel | bias] contiguous: one sum
+        if (rc == VAEK_OK) rc = launch_sum_slabs(slab, slab_stride, f.S, dw, nk, st0);
+        if (rc == VAEK_OK && dbias) rc = launch_sum_slabs(slab + nk, slab_stride, f.S, dbias, c_out, st0);
         return rc;
     }
     g.M = 16 * c_in + 1; g.N = c_out; g.K = (int)pixels;
