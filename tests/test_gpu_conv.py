@@ -146,7 +146,7 @@ def test_conv2d_weight_grad_matches_the_oracle(B, S, cin, cout):
     assert np.max(np.abs(db - want_b)) <= 1e-2 * np.max(np.abs(want_b))
 
 
-@pytest.mark.parametrize("B,S,c", [(8, 64, 32), (3, 10, 8), (5, 6, 64), (2, 4, 256), (1, 2, 1)])
+@pytest.mark.parametrize("B,S,c", [(8, 64, 32), (3, 10, 8), (5, 6, 64), (2, 4, 256), (1, 2, 1), (3, 16, 16), (1, 8, 4), (2, 24, 128)])
 def test_one_channel_layers_stream_in_exact_float32(B, S, c):
     """A 1 <-> c channel layer (config 5's first convolution, last transposed convolution, and their gradients) runs in streaming
     f32 kernels, not bf16 GEMMs: 1e-5 of the result's scale against the oracle, masks and relu included, ragged sizes included."""

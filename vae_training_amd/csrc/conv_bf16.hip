@@ -571,6 +571,75 @@ __global__ __launch_bounds__(256) void thin_conv_t_fwd4_kernel(const ThinArgs g,
         }
     }
 }
+// The strip form (input width a multiple of 4): C / 4 lanes take FOUR input pixels of a row at once -- 3 x 6 neighbourhood loads for 16
+// outputs instead of 4 x 9, one index decode and one set of row / column bounds per strip.  (The one-pixel form above spent 290
+// instructions per lane and pixel, most of them addresses and bounds: it ran at 1.7 TB/s with its traffic already at the minimum.)
+__global__ __launch_bounds__(256) void thin_conv_t_fwd4s_kernel(const ThinArgs g, const int relu) {
+    const int C = g.C, LP = C / 4, SW = g.W / 4;         // strips per input row
+    unsigned lb = blockIdx.x;
+    if (gridDim.x % 8 == 0) lb = (lb % 8) * (gridDim.x / 8) + lb / 8;      // XCD-contiguous, as above
+    const long long gid = (long long)lb * 256 + threadIdx.x, groups = (long long)gridDim.x * 256 / LP;
+    const int lg = (int)(gid % LP);
+    float4 kk[16];
+#pragma unroll
+    for (int tp = 0; tp < 16; ++tp) kk[tp] = *reinterpret_cast<const float4*>(g.w + tp * C + 4 * lg);
+    const float b = g.bias ? g.bias[0] : 0.f;
+    const long long strips = (long long)g.B * g.H * SW, rounds = (strips + groups - 1) / groups;
+    for (long long it = 0; it < rounds; ++it) {
+        const long long sidx = gid / LP + it * groups;
+        const bool live = sidx < strips;
+        const long long sc = live ? sidx : strips - 1;
+        const int n = (int)(sc / (g.H * SW)), rem = (int)(sc % (g.H * SW)), i = rem / SW, j0 = 4 * (rem % SW);
+        float4 v[3][6];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int yy = i - 1 + r;
+            const bool rv = yy >= 0 && yy < g.H;
+            const float* rowp = g.x + ((long long)n * g.H + min(max(yy, 0), g.H - 1)) * g.W * C + 4 * lg;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const int xx = j0 - 1 + c;
+                const bool in = rv && xx >= 0 && xx < g.W;
+                const float4 f = *reinterpret_cast<const float4*>(rowp + (long long)min(max(xx, 0), g.W - 1) * C);
+                v[r][c] = in ? f : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        float o[2][8];                                    // [output row parity][8 consecutive output columns]
+#pragma unroll
+        for (int px = 0; px < 4; ++px)
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int th = 0; th < 2; ++th)
+#pragma unroll
+                        for (int tw = 0; tw < 2; ++tw) {
+                            const float4 f = v[1 + pp - th][1 + px + qq - tw], k4 = kk[(1 - pp + 2 * th) * 4 + (1 - qq + 2 * tw)];
+                            acc = fmaf(f.x, k4.x, acc); acc = fmaf(f.y, k4.y, acc); acc = fmaf(f.z, k4.z, acc); acc = fmaf(f.w, k4.w, acc);
+                        }
+                    for (int sft = LP >> 1; sft >= 1; sft >>= 1) acc += __shfl_xor(acc, sft, 64);
+                    o[pp][2 * px + qq] = acc + b;
+                }
+        if (live && lg == 0) {
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const long long off = ((long long)n * 2 * g.H + 2 * i + pp) * 2 * g.W + 2 * j0;       // 8 floats: 32-byte aligned
+                float r8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r8[e] = relu ? fmaxf(o[pp][e], 0.f) : o[pp][e];
+                if (g.mask) {
+                    const float4 m0 = *reinterpret_cast<const float4*>(g.mask + off), m1 = *reinterpret_cast<const float4*>(g.mask + off + 4);
+                    r8[0] = m0.x > 0.f ? r8[0] : 0.f; r8[1] = m0.y > 0.f ? r8[1] : 0.f; r8[2] = m0.z > 0.f ? r8[2] : 0.f; r8[3] = m0.w > 0.f ? r8[3] : 0.f;
+                    r8[4] = m1.x > 0.f ? r8[4] : 0.f; r8[5] = m1.y > 0.f ? r8[5] : 0.f; r8[6] = m1.z > 0.f ? r8[6] : 0.f; r8[7] = m1.w > 0.f ? r8[7] : 0.f;
+                }
+                *reinterpret_cast<float4*>(g.y + off) = make_float4(r8[0], r8[1], r8[2], r8[3]);
+                *reinterpret_cast<float4*>(g.y + off + 4) = make_float4(r8[4], r8[5], r8[6], r8[7]);
+            }
+        }
+    }
+}
 // kernel gradient with a one-channel gathered tensor: part[block][tap or 16 = bias][o] = sum over the block's pixels of
 // x_window[p, tap] dy[p, o]; thread = (pixel lane, o), the lanes of a block meet through LDS, a fixed-order sum over the blocks follows
 __global__ __launch_bounds__(256) void thin_conv_wgrad_kernel(const ThinArgs g, float* part) {
@@ -1010,7 +1079,9 @@ extern "C" int vaek_conv2d_transpose_forward(const float* y, const float* w, con
         ta.B = batch; ta.H = height; ta.W = width; ta.C = c_in; ta.pixels = 4 * M;
         {
             ProfScope ps("conv_t_fwd_thin", (hipStream_t)stream);
-            if ((c_in & (c_in - 1)) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0 && (reinterpret_cast<uintptr_t>(mask) & 7) == 0)
+            if ((c_in & (c_in - 1)) == 0 && width % 4 == 0 && aligned16(out) && aligned16(mask))
+                launch_k(ps, thin_conv_t_fwd4s_kernel, dim3((unsigned)std::min<long long>(8192, (M / 4 * (c_in / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
+            else if ((c_in & (c_in - 1)) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0 && (reinterpret_cast<uintptr_t>(mask) & 7) == 0)
                 launch_k(ps, thin_conv_t_fwd4_kernel, dim3((unsigned)std::min<long long>(8192, (M * (c_in / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
             else
                 launch_k(ps, thin_conv_t_fwd_kernel, dim3((unsigned)std::min<long long>(16384, (4 * M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
