@@ -69,6 +69,31 @@ def test_vaemodel_steps_match_oracle(tmp_path, dataset, enc, dec, latent, pad, e
     assert np.max(np.abs(host(mu) - mu_ref)) <= 1e-4 * max(1.0, np.max(np.abs(mu_ref)))
 
 
+@pytest.mark.parametrize("dataset,latent,pad", [("linear_gaussian", 8, 5), ("sigmoid", 6, 3)])
+def test_warm_start_starts_near_the_data_manifold(tmp_path, dataset, latent, pad):
+    """-ws (vae.py:62-107): the warm-started model's first loss is far below the cold-started one's on the same batch, and it trains."""
+    from vae_training_amd.run import get_dataset, parse_arguments
+    from vae_training_amd.vae import VAEModel
+    from vae_training_amd.networks import VAE
+    args = parse_arguments(["t", "--dataset", dataset, "--padding_dim", str(pad), "-dd", "2" if dataset == "sigmoid" else "3", "-ds", "2"])
+    first = {}
+    for ws in (False, True):
+        ds = get_dataset(dataset, 2, pad, 256, args)
+        m = VAEModel(dirname=str(tmp_path), num_batches=4, num_epochs=1, batch_size=256, learning_rate=1e-3, layer_sizes="",
+                     encoder_layer_sizes="", state_dict=None, data_fn=None, epsilon=-3.0, tqdm=False, dataset=ds, latent_dimension=latent,
+                     tunable_decoder_var=True, dataset_name=dataset, warm_start=ws, latent_off_dimension=1)
+        x = ds.get_batch(256)
+        z = m.sample_latent(m.get_key(), 256)
+        z1, z2 = z[:, :latent].contiguous(), z[:, latent:].contiguous()
+        losses = []
+        for _ in range(5):
+            m.optimizer, m.model, loss = VAE.train_step(m.optimizer, x, z1, z2, m.epsilon)
+            losses.append(float(loss))
+        assert np.isfinite(losses).all() and losses[-1] < losses[0]
+        first[ws] = losses[0]
+    assert first[True] < 0.5 * first[False], first
+
+
 def test_run_py_end_to_end_and_resume(tmp_path, monkeypatch, capsys):
     """`python run.py NAME ...` side effects (utils.py:46-60, model.py:246-255) and a --state_dict resume."""
     from vae_training_amd import run, utils

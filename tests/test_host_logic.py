@@ -202,3 +202,45 @@ def test_engine_refuses_to_run_without_gpu():
     from vae_training_amd.engine import Engine
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         Engine(8, 4, 2)
+
+
+def test_warm_start_initialisation_follows_the_reference():
+    """vae.py:62-107 (-ws): the one-layer encoder / decoder start at the data manifold's own maps plus small noise."""
+    import types
+
+    import torch
+
+    from vae_training_amd import random as vr
+    from vae_training_amd.networks import VAE
+    from vae_training_amd.vae import warm_start_params
+    # linear_gaussian: dimension 3 (= intrinsic), padding 4 -> data size 7, latent 6, one extra latent column
+    A = torch.tensor([[1.0, 0.2, 0.0], [0.0, 1.5, 0.3], [0.4, 0.0, 0.8]])
+    ds = types.SimpleNamespace(dim=3, dimension=7, A=A)
+    mod = VAE.partial(epsilon=-1.0, encoder_layer_sizes=[6], decoder_layer_sizes=[7], tunable_decoder_var=True, dataset_name="linear_gaussian")
+    _, p = mod.init_by_shape(vr.PRNGKey(0), [(7,), (6,), (7,)])
+    warm_start_params(p, vr.PRNGKey(3), ds, "linear_gaussian", 6, 7, latent_off_dimension=1)
+    dec = p["Decoder"]["FC0"]["kernel"]                     # [L, D] = (the [D, L] constant)^T
+    assert dec.shape == (6, 7)
+    assert torch.allclose(dec[:3, :3], A.T, atol=0.06) and dec[4:, :].abs().max() < 0.06 and dec[:, 3:].abs().max() < 0.06
+    assert dec[3, :3].abs().max() > 0.06                    # the extra latent column is N(0, 1), not noise-sized
+    enc = p["Encoder"]["FC0"]["kernel"]                     # [D, L]
+    assert enc.shape == (7, 6) and torch.allclose(enc[:3, :3], torch.linalg.pinv(A).T, atol=0.06)
+    assert enc[3:, :].abs().max() < 0.06 and enc[:, 3:].abs().max() < 0.06
+    ep = p["epsilon_p"]
+    assert torch.all((ep[:4] + 3).abs() < 0.5) and torch.all(ep[4:].abs() < 0.5)
+    # sigmoid: dimension 2 -> data size 2 + 1 + 3 padding = 6 = latent size
+    ds = types.SimpleNamespace(dim=2, dimension=6)
+    mod = VAE.partial(epsilon=-1.0, encoder_layer_sizes=[6], decoder_layer_sizes=[6], tunable_decoder_var=False, dataset_name="sigmoid")
+    _, p = mod.init_by_shape(vr.PRNGKey(0), [(6,), (6,), (6,)])
+    warm_start_params(p, vr.PRNGKey(4), ds, "sigmoid", 6, 6)
+    want = torch.eye(6); want[3:, 3:] = 0
+    for name in ("Encoder", "Decoder"):
+        assert (p[name]["FC0"]["kernel"] - want).abs().max() < 0.6 and (p[name]["FC0"]["kernel"] - want).abs().mean() < 0.15
+    assert p["SigDecoder"]["FC0"]["kernel"].abs().max() < 0.6
+    assert torch.all(p["epsilon_p"][:3].abs() < 0.5) and torch.all((p["epsilon_p"][3:] + 3).abs() < 0.5)
+    # hidden layers: the reference's shapes do not fit -> a clear error, not a silently wrong model
+    mod = VAE.partial(epsilon=-1.0, encoder_layer_sizes=[5, 6], decoder_layer_sizes=[5, 7], tunable_decoder_var=False, dataset_name="linear_gaussian")
+    _, p = mod.init_by_shape(vr.PRNGKey(0), [(7,), (6,), (7,)])
+    ds = types.SimpleNamespace(dim=3, dimension=7, A=A)
+    with pytest.raises(ValueError):
+        warm_start_params(p, vr.PRNGKey(3), ds, "linear_gaussian", 6, 7, latent_off_dimension=1)

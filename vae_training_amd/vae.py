@@ -1,9 +1,8 @@
 """VAEModel, the reference's per-experiment wrapper (vae.py:15-209): same constructor signature,
 attributes (.model, .optimizer, .key, .vae_losses, .epsilon, .current_epsilon, .latent_dimension)
 and methods (train_one_batch :123-130, compute_model_stats :132-141, sample_batch :191-201,
-model_save_data :203-209).  Warm start (:62-107) and the correlation ratio (:143-179) are out of
-scope: the former uses removed jax APIs and no shipped script sets it,
-the latter iterates an always-empty list."""
+model_save_data :203-209), and the warm start of -ws (:62-107: host-side initialisation only, SURVEY.md 8f rank 4's sibling).
+The correlation ratio (:143-179) is out of scope: it iterates an always-empty list."""
 from __future__ import annotations
 
 import math
@@ -16,6 +15,60 @@ from .networks import VAE, Model
 from .optim import Adam
 
 
+def warm_start_params(params, key, dataset, dataset_name, latent_dimension, data_size, latent_off_dimension=0):
+    """The reference's -ws initialisation (vae.py:62-107) on the nested parameter dict, in place: the one-layer encoder / decoder
+    start at the data manifold's own maps plus small noise.
+      sigmoid (:63-79):          Encoder / Decoder kernels = identity with the [dim + 1:, dim + 1:] block zeroed, + 0.1 N(0, 1);
+                                 SigDecoder kernel = 0.1 N(0, 1); epsilon_p = -3 on [dim + 1:], 0 before, + 0.1 N(0, 1).
+      linear_gaussian (:81-106): Decoder kernel = ([A | N(0, 1) extra columns | 0] stacked over zero padding rows + 0.01 N(0, 1))^T,
+                                 Encoder kernel = (pinv(A) padded with zero rows / columns + 0.01 N(0, 1))^T,
+                                 epsilon_p = -3 on the first A.shape[1] + latent_off_dimension entries, 0 after, + 0.1 N(0, 1).
+    Every draw uses `key` itself, as the reference does (self.key, never split there).  Other datasets: untouched, like the
+    reference.  Shapes that the reference's concatenations would reject (hidden layers; an intrinsic dimension != dimension)
+    raise ValueError here."""
+    L = latent_dimension
+    normal = lambda shape: vrandom.normal(key, shape, "cpu")
+
+    def put(path, value):
+        leaf = params
+        for name in path[:-1]:
+            leaf = leaf[name]
+        if tuple(leaf[path[-1]].shape) != tuple(value.shape):
+            raise ValueError(f"warm start: {'/'.join(path)} has shape {tuple(leaf[path[-1]].shape)}, the warm-start value {tuple(value.shape)} "
+                             "(it needs the one-layer encoder and decoder of the reference's -ws experiments)")
+        leaf[path[-1]] = value.to(torch.float32)
+
+    if dataset_name == "sigmoid":
+        dim, full = dataset.dim, int(dataset.dimension)
+        if L != full:
+            raise ValueError(f"warm start (sigmoid): latent_dim {L} must equal the data dimension {full} (vae.py:64)")
+        eye = torch.eye(L)
+        eye[dim + 1:, dim + 1:] = 0.0
+        var = torch.zeros(L)
+        var[dim + 1:] = -3.0
+        put(("Decoder", "FC0", "kernel"), eye + 0.1 * normal((L, full)))
+        put(("SigDecoder", "FC0", "kernel"), 0.1 * normal((L, full)))
+        put(("epsilon_p",), var + 0.1 * normal((L,)))
+        put(("Encoder", "FC0", "kernel"), eye + 0.1 * normal((full, L)))
+    elif dataset_name == "linear_gaussian":
+        dim, off = dataset.dim, int(latent_off_dimension)
+        A = dataset.A.detach().to("cpu", torch.float32)
+        if not dim + off < L:
+            raise ValueError(f"warm start (linear_gaussian): dimension {dim} + latent_off_dimension {off} must be < latent_dim {L} (vae.py:82)")
+        if A.shape[1] != dim:
+            raise ValueError("warm start (linear_gaussian): the reference's concatenations need intrinsic_dimension == dimension")
+        dec = torch.cat([A, normal((dim, off)), torch.zeros(dim, L - dim - off)], dim=1)
+        dec = torch.cat([dec, torch.zeros(data_size - dim, L)], dim=0) + 0.01 * normal((int(dataset.dimension), L))
+        put(("Decoder", "FC0", "kernel"), dec.T.contiguous())
+        enc = torch.cat([torch.linalg.pinv(A), torch.zeros(L - dim, dim)], dim=0)
+        enc = torch.cat([enc, torch.zeros(L, data_size - dim)], dim=1) + 0.01 * normal((L, int(dataset.dimension)))
+        put(("Encoder", "FC0", "kernel"), enc.T.contiguous())
+        var = torch.zeros(L)
+        var[:A.shape[1] + off] = -3.0
+        put(("epsilon_p",), var + 0.1 * normal((L,)))
+    return params
+
+
 class VAEModel(GenerativeModel):
     def __init__(self, dirname, num_batches, num_epochs, batch_size, learning_rate, layer_sizes,
                  encoder_layer_sizes, state_dict, data_fn, epsilon, tqdm, dataset, latent_dimension,
@@ -25,9 +78,6 @@ class VAEModel(GenerativeModel):
                          learning_rate=learning_rate, latent_distribution="gaussian",
                          latent_dimension=latent_dimension, dataset=dataset, state_dict=state_dict,
                          data_fn=data_fn, tqdm=tqdm)
-        if warm_start:
-            raise NotImplementedError("-ws/--warm_start is out of scope (reference vae.py:62-107 relies on the "
-                                      "removed jax.ops.index_update; no shipped experiment script uses it)")
         self.fast_loop = fast_loop
         self.epsilon = epsilon
         self.current_epsilon = epsilon
@@ -41,6 +91,8 @@ class VAEModel(GenerativeModel):
                                  tunable_decoder_var=tunable_decoder_var, dataset_name=dataset_name,
                                  device=device, world=world, rank=rank, force_generic=force_generic, dtype=dtype)
         _, initial_params = vae_module.init_by_shape(vae_key, [(data_size,), (latent_dimension,), (data_size,)])
+        if warm_start:
+            warm_start_params(initial_params, self.key, dataset, dataset_name, latent_dimension, data_size, latent_off_dimension)
         self.model = Model(vae_module, initial_params)
         self.optimizer = Adam(learning_rate=self.learning_rate).create(self.model, exchange=exchange,
                                                                        global_batch=global_batch)
