@@ -333,7 +333,8 @@ def _checked_conv_calls(monkeypatch, log):
 
 
 @pytest.mark.parametrize("size,widths,L,B,tdv", [(16, (4, 8, 8, 16), 5, 6, True), (32, (8, 16, 16, 32), 7, 4, False), (64, (4, 8, 8, 16), 8, 3, True),
-                                                 (64, (32, 64, 128, 256), 32, 2, True)])        # the last: BASELINE config 5's own widths
+                                                 (64, (32, 64, 128, 256), 32, 2, True),         # BASELINE config 5's own widths
+                                                 (48, (8, 16, 16, 32), 6, 2, True)])            # 48 x 48: no power-of-two sizes -- the general forms
 def test_conv_vae_loss_and_every_gradient_leaf(size, widths, L, B, tdv, monkeypatch):
     """The whole convolutional VAE -- forward, ELBO, backward assembled from the library's blocks.
     (i) Every one of the 23 convolution calls of the step, on the inputs it actually received, against torch float64 with the
