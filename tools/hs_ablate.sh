@@ -3,7 +3,7 @@
 set -e
 cd $GRAFT_REPO_ROOT/vae_training_amd/csrc
 mkdir -p /tmp/hsab_common
-for f in api gemm_f32 gemm_bf16 gemm_skinny16 elbo fused_small fused_mfma comm rng microbench; do
+for f in $(ls *.hip | sed "s/\.hip$//"); do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -c $f.hip -o /tmp/hsab_common/$f.o &
 done; wait
 for ab in "$@"; do

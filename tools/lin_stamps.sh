@@ -1,7 +1,7 @@
 # Diagnostic build (-DVAEK_LIN_STAMPS): where the updater workgroup of vaek_train_steps spends its cycles.
 set -e
 cd $GRAFT_REPO_ROOT/vae_training_amd/csrc
-mkdir -p /tmp/linst && for f in api gemm_f32 gemm_bf16 gemm_bf16s gemm_skinny16 linear_moments elbo fused_small fused_mfma fused_mlp1 comm rng microbench; do
+mkdir -p /tmp/linst && for f in $(ls *.hip | sed "s/\.hip$//"); do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -DVAEK_LIN_STAMPS -c $f.hip -o /tmp/linst/$f.o &
 done; wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/linst/libvaek.so /tmp/linst/*.o
