@@ -277,8 +277,6 @@ def _bf16_emulation_grads(cfg, p, x, z1, z2):
     return loss.item(), {k: t.grad.numpy() for k, t in tp.items()}
 
 
-@pytest.mark.parametrize("size,widths,L,B,tdv", [(16, (4, 8, 8, 16), 5, 6, True), (32, (8, 16, 16, 32), 7, 4, False), (64, (4, 8, 8, 16), 8, 3, True),
-                                                 (64, (32, 64, 128, 256), 32, 2, True)])        # the last: BASELINE config 5's own widths
 def _checked_conv_calls(monkeypatch, log):
     """Wrap the three convolution entry points conv_vae.py calls: every call is compared, on ITS OWN inputs, with torch float64 with
     the operands rounded to bf16 where the kernel rounds them (not at all for the one-channel streaming kernels)."""

@@ -41,6 +41,21 @@ def _run_pipelined(eng, cfg, p, batches, lr):
     return params, grads, m, v, int(step.item()), host(ring)[:len(batches)]
 
 
+def _leafwise_grads_of_the_first_step(cfg, eng, p0, batch, lr):
+    """grads[:P] of ONE vaek_train_steps step from p0, leaf by leaf against the oracle's loss_and_grad (networks.py:99): a small
+    leaf (epsilon, epsilon_p, a bias) must be right on its OWN scale, not on the scale of the whole vector."""
+    params, grads, m, v, step, losses = _run_pipelined(eng, cfg, p0, [batch], lr)
+    loss, g = O.loss_and_grad(cfg, p0, *batch)
+    got, want = host(grads), O.flatten(cfg, g)
+    assert abs(got[eng.P] - loss) <= 1e-5 * abs(loss)
+    assert np.max(np.abs(got[:eng.P] - want)) <= 2e-5 * np.max(np.abs(want)), "gradient, whole vector"
+    worst = {}
+    for name, (off, shape) in eng.leaves.items():
+        k = int(np.prod(shape))
+        worst[name] = float(np.max(np.abs(got[off:off + k] - want[off:off + k])) / (np.max(np.abs(want[off:off + k])) + 1e-30))
+    assert max(worst.values()) <= 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+
+
 @pytest.mark.parametrize("name,B,n", [("c1_linear_L20", 16, 6), ("c1_linear_L2", 16, 6), ("linear_notdv", 8, 5),
                                       ("c1_linear_L20", 1000, 7), ("c1_linear_L20", 256, 1), ("c1_linear_L2", 777, 2)])
 def test_pipelined_steps_match_the_oracle(name, B, n):
@@ -48,6 +63,7 @@ def test_pipelined_steps_match_the_oracle(name, B, n):
     p, batches = _problem(cfg, dk, B, n)
     eng = engine_for(cfg, B)
     assert eng.supports_train_steps()
+    _leafwise_grads_of_the_first_step(cfg, eng, p, batches[0], lr)
     params, grads, m, v, step, losses = _run_pipelined(eng, cfg, p, batches, lr)
     st = O.adam_init(p)
     for i, (x, z1, z2) in enumerate(batches):
@@ -85,6 +101,7 @@ def test_metric_size_and_agreement_with_the_step_by_step_kernels():
     B, n = 65536, 4
     p0, batches = _problem(cfg, dk, B, n)
     eng = engine_for(cfg, B)
+    _leafwise_grads_of_the_first_step(cfg, eng, p0, batches[0], lr)
     params, grads, m, v, step, losses = _run_pipelined(eng, cfg, p0, batches, lr)
     p, st = dict(p0), O.adam_init(p0)
     for i, (x, z1, z2) in enumerate(batches):

@@ -48,11 +48,12 @@ if persist:
     print("updater, last step of the launch (s_memtime ticks):")
     print(f"   publish params               {t[9] - t[0]:8d}")
     print(f"   wait for the reducers        {t[8] - t[9]:8d}")
-    print(f"   expand M                     {t[1] - t[8]:8d}")
+    print(f"   M into registers             {t[1] - t[8]:8d}")
 else:
     print("updater phases (ticks):")
     print(f"   load params + expand M       {t[1] - t[0]:8d}")
-names = ["e^{lv/2}", "SM", "P1", "G, dWd, partial sums", "tree reduce", "outputs + Adam"]
+names = (["SM, P1 (wave 0)", "barrier", "G, dWd, gradients, partial sums", "barrier", "outputs + Adam"] if persist else
+         ["e^{lv/2}", "SM", "P1", "G, dWd, partial sums", "tree reduce", "outputs + Adam"])
 for i, n in enumerate(names):
     print(f"   {n:28s} {t[i + 2] - t[i + 1]:8d}")
 print("   total", t[7] - t[0])

@@ -64,6 +64,8 @@ constexpr int kLinReduceWgs = 24;                 // workgroups per set, each su
 constexpr int kLinCommBanks = 4;
 struct LinComm { unsigned long long* peer[kMaxWorld]; int world, rank, ng2; };     // ng2 = granules per (bank, source rank) = 2 NO
 
+constexpr int kLinShards = 8, kLinShardStride = 32;   // words
+struct LinPtrs { const float* x[64]; const float* z1[64]; const float* z2[64]; };    // batch pointers of a persistent launch (kernarg)
 struct LinArgs {
     // roles by blockIdx.x: [0, has_update) the updater, then n_reduce reducers, then n_stream streamers
     int has_update, n_reduce, n_stream;
@@ -74,9 +76,12 @@ struct LinArgs {
     const double* M_in;
     // ---- persistent form: n_steps batches, pointer tables in device memory, one slot per batch, arrival counters
     int persistent, n_steps, sets;                // sets: reducer sets taking alternate batches
-    const float* const* xs; const float* const* z1s; const float* const* z2s;
     float* partial_base; double* M_base;                                          // slot n at + n * ntiles * NO resp. + n * NO
-    unsigned* cnt_stream; unsigned* cnt_reduce; unsigned* status;                 // [n_steps], [n_steps], [1]; zeroed before the launch
+    // arrival counters.  cnt_stream: kLinShards shards per batch, each on a 128-byte line of its own (a streamer adds to shard
+    // blockIdx & 7: 228 adders on ONE word serialise at the memory side -- the reducers woke 8 us after the last streamer had
+    // signalled); cnt_reduce: one word per batch.  All zero when a launch starts: the updater re-zeroes what the launch used as
+    // its last act (everybody else is provably done with them by then), lin_init_kernel zeroes them once per workspace.
+    unsigned* cnt_stream; unsigned* cnt_reduce; unsigned* status;                 // status: sticky, outside the zeroed range
     // ---- updater
     float* params; float* grads; float* m; float* v; int32_t* step_dev; float lr;
     float inv_bt, eps_cli, rows, rows_over_bt; int off_eps, P;
@@ -166,6 +171,33 @@ __device__ __forceinline__ void lin_wait_count(const unsigned* cnt, unsigned tar
     __syncthreads();
 }
 
+// the same on a batch's SHARDED streamer counter: thread 0 keeps all shards' loads in flight together and compares their sum
+__device__ __forceinline__ void lin_wait_shards(const unsigned* cnt, unsigned target, unsigned* status, unsigned tag) {
+    if (threadIdx.x == 0) {
+        unsigned spins = 0, seen;
+        for (;;) {
+            unsigned v[kLinShards];
+#pragma unroll
+            for (int k = 0; k < kLinShards; ++k) v[k] = __hip_atomic_load(cnt + k * kLinShardStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seen = 0;
+#pragma unroll
+            for (int k = 0; k < kLinShards; ++k) seen += v[k];
+            if (seen >= target) break;
+            __builtin_amdgcn_s_sleep(4);
+            if ((++spins & 1023u) == 0) {
+                if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if (spins > (1u << 21)) {
+                    unsigned expect = 0;
+                    __hip_atomic_compare_exchange_strong(status, &expect, 0x80000000u | tag | (seen & 0xffffu), __ATOMIC_RELAXED,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // one output of M across the ranks: publish this rank's value, collect everybody's, add in rank order (bounded spins)
 __device__ __forceinline__ double lin_sum_over_ranks(const LinComm& c, unsigned epoch, int o, double v, unsigned* status) {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(v), tag = (unsigned long long)epoch << 32;
@@ -202,127 +234,209 @@ __device__ __forceinline__ double lin_sum_over_ranks(const LinComm& c, unsigned 
 }
 
 // ---- streamer pieces ------------------------------------------------------------------------------------------------------------
-// LDS slot of one T-sample tile: the three tensors' tiles exactly as they lie in HBM (row-major [T][L] / [T][D]), each
-// padded to whole 8 KB (one pass of the 512-thread copy: every thread issues the same number of loads), the validity column
-// V[T] (the "1" feature; 0 for rows past the batch end) and a zero word.
-struct LinSlot {
-    int z1_b, x_b, oX, oZ2, oV, oC, bytes, passes;
-    __device__ __host__ LinSlot(int D, int L, int T) {
-        z1_b = (L * 4 * T + 8191) / 8192 * 8192; x_b = (D * 4 * T + 8191) / 8192 * 8192;
-        oX = z1_b; oZ2 = oX + x_b; oV = oZ2 + x_b; oC = oV + 4 * T; bytes = (oC + 16 + 255) / 256 * 256;
-        passes = (z1_b + 2 * x_b) / 8192;
+// LDS image of one T-sample tile: the three tensors' tiles exactly as they lie in HBM (row-major [T][L] / [T][D]), each region a
+// whole number of 1 KB PIECES (one LDS-DMA wave-instruction: 64 lanes x 16 bytes).  Piece p of a tile goes to wave p % 8.  The
+// validity column V[T] (the "1" feature; 0 for rows past the batch end) and a zero word live outside the slots: a full tile's
+// column is all ones and is written once per launch.
+struct LinTile {
+    int nz1, nx, np, oX, oZ2, bytes;
+    __device__ __host__ LinTile(int D, int L, int T) {
+        nz1 = (L * 4 * T + 1023) >> 10; nx = (D * 4 * T + 1023) >> 10; np = nz1 + 2 * nx;
+        oX = (nz1 << 10) + 80;      // + 20 banks: the feature block that mixes z1 and x columns then reads conflict-free in 3 k-steps of 4 (was 2 of 4)
+        oZ2 = oX + (nx << 10); bytes = (oZ2 + (nx << 10) + 255) & ~255;
     }
 };
 
-__device__ __forceinline__ void lin_issue_tile(const LinArgs& a, const LinSlot& sl, const float* x, const float* z1, const float* z2,
-                                               int tile, char* slot, int t, int wave) {
-    const long long row0 = (long long)tile * a.T;
-    auto copy = [&](const float* src, int cols, int bytes, int lds_off) {
-        const long long tot = (long long)a.B * cols * 4, base = row0 * cols * 4;
-        // the last 16-byte piece this tile may fetch: the tile's own (the slot's padding up to whole 8 KB passes re-reads it -- a
-        // line this CU has just fetched -- instead of pulling the NEXT tile's rows through another XCD's L2: 10 % of the HBM reads),
-        // and never past the tensor's last whole 16 bytes; what a clamped piece brings lands in LDS nobody reads, in rows that are
-        // zeroed afterwards, or in the tensor's last <= 3 floats, which lin_fix_tile rewrites
-        const long long last = min(tot & ~15ll, base + (long long)a.T * cols * 4) - 16;
-        for (int i = 0; i < bytes / 8192; ++i) {
-            long long off = base + i * 8192 + t * 16;
-            off = off <= last ? off : last;
-            lin_glds16(reinterpret_cast<const char*>(src) + off, slot + lds_off + i * 8192 + wave * 1024);
-        }
-    };
-    copy(z1, a.L, sl.z1_b, 0);
-    copy(x, a.D, sl.x_b, sl.oX);
-    copy(z2, a.D, sl.x_b, sl.oZ2);
+// piece p (wave-uniform) of tile `tile`: 1 KB of z1 / x / z2 from HBM straight into the slot
+__device__ __forceinline__ void lin_issue_piece(const LinArgs& a, const LinTile& tl, const float* x, const float* z1, const float* z2,
+                                                int tile, int p, char* slot, int lane) {
+    const float* src; int cols, idx, lds_off;
+    if (p < tl.nz1) { src = z1; cols = a.L; idx = p; lds_off = 0; }
+    else if (p < tl.nz1 + tl.nx) { src = x; cols = a.D; idx = p - tl.nz1; lds_off = tl.oX; }
+    else { src = z2; cols = a.D; idx = p - tl.nz1 - tl.nx; lds_off = tl.oZ2; }
+    const long long tot = (long long)a.B * cols * 4, base = (long long)tile * a.T * cols * 4;
+    // the last 16-byte piece this tile may fetch: the tile's own (a region's padding up to whole pieces re-reads it -- a line this
+    // CU has just fetched -- instead of pulling the NEXT tile's rows through another XCD's L2), and never past the tensor's last
+    // whole 16 bytes; what a clamped piece brings lands in LDS nobody reads, in rows that are zeroed afterwards, or in the
+    // tensor's last <= 3 floats, which lin_fix_ragged rewrites
+    const long long last = min(tot & ~15ll, base + (long long)a.T * cols * 4) - 16;
+    long long off = base + idx * 1024 + lane * 16;
+    off = off <= last ? off : last;
+    lin_glds16(reinterpret_cast<const char*>(src) + off, slot + lds_off + idx * 1024);
 }
 
-// after the tile has landed: the validity column, the zero word, and for the last tile of a ragged batch the rows past the end
-__device__ __forceinline__ void lin_fix_tile(const LinArgs& a, const LinSlot& sl, const float* x, const float* z1, const float* z2,
-                                             int tile, char* slot, int t) {
+// The same with everything that does not depend on the piece worked out once per tile (the persistent streamers issue the pieces
+// of a tile one by one between the k-steps of an earlier one: what is left per piece is a handful of scalar selects, one 64-bit
+// add, one clamp).  All members are wave-uniform.
+struct LinTileSrc {
+    const char *z1, *x, *z2; long long baseL, lastL, baseD, lastD; char* slot; bool on;
+    __device__ __forceinline__ void prepare(const LinArgs& a, const float* px, const float* pz1, const float* pz2, int tile, char* slot_) {
+        auto uni = [](const float* q) {
+            const unsigned long long u = (unsigned long long)q;
+            // (readfirstlane returns int: through unsigned, or a low word >= 2^31 sign-extends into the high one)
+            return reinterpret_cast<const char*>((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)u) |
+                                                 ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(u >> 32)) << 32));
+        };
+        z1 = uni(pz1); x = uni(px); z2 = uni(pz2); slot = slot_; on = true;
+        const long long rows = (long long)tile * a.T;
+        const long long totL = (long long)a.B * a.L * 4, totD = (long long)a.B * a.D * 4;
+        baseL = rows * a.L * 4; baseD = rows * a.D * 4;
+        lastL = min(totL & ~15ll, baseL + (long long)a.T * a.L * 4) - 16;
+        lastD = min(totD & ~15ll, baseD + (long long)a.T * a.D * 4) - 16;
+    }
+    __device__ __forceinline__ void issue(const LinTile& tl, int p, int lane) const {      // piece p (wave-uniform)
+        const char* src; long long base, last; int idx, lds_off;
+        if (p < tl.nz1) { src = z1; base = baseL; last = lastL; idx = p; lds_off = 0; }
+        else if (p < tl.nz1 + tl.nx) { src = x; base = baseD; last = lastD; idx = p - tl.nz1; lds_off = tl.oX; }
+        else { src = z2; base = baseD; last = lastD; idx = p - tl.nz1 - tl.nx; lds_off = tl.oZ2; }
+        long long off = base + idx * 1024 + lane * 16;
+        off = off <= last ? off : last;
+        lin_glds16(src + off, slot + lds_off + idx * 1024);
+    }
+};
+
+// the last tile of a ragged batch, after it has landed: the tensors' last floats behind their last whole 16 bytes, zeros in the
+// rows past the batch end
+__device__ __forceinline__ void lin_fix_ragged(const LinArgs& a, const LinTile& tl, const float* x, const float* z1, const float* z2,
+                                               int tile, char* slot, int t) {
     const int T = a.T;
     const long long row0 = (long long)tile * T;
     const int valid = (int)min((long long)T, (long long)a.B - row0), D = a.D, L = a.L;
-    if (t < T) reinterpret_cast<float*>(slot + sl.oV)[t] = t < valid ? 1.f : 0.f;
-    if (t == 0) *reinterpret_cast<float*>(slot + sl.oC) = 0.f;
     if (valid < T) {
         auto patch_tail = [&](const float* src, int cols, int lds_off) {     // floats behind the tensor's last whole 16 bytes
             const long long tot = (long long)a.B * cols * 4, full = tot & ~15ll, base = row0 * cols * 4;
             if (t < (int)((tot - full) / 4) && full >= base) reinterpret_cast<float*>(slot + lds_off)[(full - base) / 4 + t] = src[full / 4 + t];
         };
-        patch_tail(z1, L, 0); patch_tail(x, D, sl.oX); patch_tail(z2, D, sl.oZ2);
+        patch_tail(z1, L, 0); patch_tail(x, D, tl.oX); patch_tail(z2, D, tl.oZ2);
         for (int e = valid * L + t; e < T * L; e += LNT) reinterpret_cast<float*>(slot)[e] = 0.f;
-        for (int e = valid * D + t; e < T * D; e += LNT) { reinterpret_cast<float*>(slot + sl.oX)[e] = 0.f; reinterpret_cast<float*>(slot + sl.oZ2)[e] = 0.f; }
+        for (int e = valid * D + t; e < T * D; e += LNT) { reinterpret_cast<float*>(slot + tl.oX)[e] = 0.f; reinterpret_cast<float*>(slot + tl.oZ2)[e] = 0.f; }
     }
     lin_barrier();
+}
+// validity column of a tile with `valid` rows
+__device__ __forceinline__ void lin_write_vcol(float* v, int T, int valid, int t) {
+    for (int r = t; r < T; r += LNT) v[r] = r < valid ? 1.f : 0.f;
+}
+
+// 16-byte write-through store (the compiler does not count it: every wait on it is ours)
+__device__ __forceinline__ void st_sc1_x4(float* p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 // M_tile = U^T U.  The SAMPLES are dealt to the waves: wave w takes samples (T / 8) w .. -- T / 32 k-steps of 4 samples -- for
 // every block of the upper block triangle, so each operand register read from LDS feeds NB (+1) MFMAs, the matrix pipes of
-// the four SIMDs carry equal loads and the NBLK accumulator chains are independent.  The eight per-wave images are then
-// summed through LDS (in wave order: deterministic) in the tile's own slot, which is dead by then, and leave as one image.
+// the four SIMDs carry equal loads and the NBLK accumulator chains are independent.  hook(j) runs between the operand reads
+// and the products of k-step j (the persistent streamers issue the LDS-DMA pieces of a later tile there: in the shadow of the
+// matrix pipe).  JT > 0: the k-step count at compile time -- the loop unrolls, the reads carry immediate offsets and the waits
+// are counted (with a run-time count hipcc waits lgkmcnt(0) before every group of products, prefetched operands included).
 constexpr int lin_scratch_bytes(int NB) { return LNW * (NB * (NB + 1) / 2) * 1024; }
-template <int NB, bool SC1>
-__device__ __forceinline__ void lin_multiply_tile(const LinArgs& a, const LinSlot& sl, char* slot, float* out, int t, int wave) {
+template <int NB, int JT, typename Hook>
+__device__ __forceinline__ void lin_tile_products(const LinArgs& a, const LinTile& tl, const char* smem, int slot_off, int v_off, int c_off,
+                                                  f32x4 (&acc)[NB * (NB + 1) / 2], int lane, int wave, Hook&& hook) {
     constexpr int NBLK = NB * (NB + 1) / 2;
-    const int lane = t & 63, g = lane >> 4, D = a.D, L = a.L;
+    const int g = lane >> 4, D = a.D, L = a.L;
     // where this lane's feature 16 u + (lane & 15) lives (byte offset of sample 0, byte stride per sample)
     int fb[NB], fs[NB];
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int f = 16 * u + (lane & 15);
-        if (f < L) { fb[u] = f * 4; fs[u] = L * 4; }
-        else if (f < L + D) { fb[u] = sl.oX + (f - L) * 4; fs[u] = D * 4; }
-        else if (f < L + 2 * D) { fb[u] = sl.oZ2 + (f - L - D) * 4; fs[u] = D * 4; }
-        else if (f == L + 2 * D) { fb[u] = sl.oV; fs[u] = 4; }
-        else { fb[u] = sl.oC; fs[u] = 0; }
+        if (f < L) { fb[u] = slot_off + f * 4; fs[u] = L * 4; }
+        else if (f < L + D) { fb[u] = slot_off + tl.oX + (f - L) * 4; fs[u] = D * 4; }
+        else if (f < L + 2 * D) { fb[u] = slot_off + tl.oZ2 + (f - L - D) * 4; fs[u] = D * 4; }
+        else if (f == L + 2 * D) { fb[u] = v_off; fs[u] = 4; }
+        else { fb[u] = c_off; fs[u] = 0; }
     }
-    f32x4 acc[NBLK];
 #pragma unroll
     for (int k = 0; k < NBLK; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     // Wave w takes samples (T / 8) w .. + T / 8 - 1 in J = T / 32 k-steps of 4.  Within a run of 16 samples lane group g takes sample
     // s + 4 g in step s: four rows apart, i.e. 16 banks with 80- and 48-byte rows, so the lane groups one ds_read_b32 services
     // together never collide; a run shorter than 16 (T / 8 not a multiple of 16: its last r < 4 steps) takes s + r g.
-    // Operands run one step ahead in a second register set, and the scheduler is told to keep it that way: left alone hipcc
-    // reuses one register set and waits out the full LDS latency before every MFMA.
-    const int J = a.T >> 5, wbase = (a.T >> 3) * wave, jfull = J & ~3;
-    float op[2][NB];
-    auto fetch = [&](int set, int j) {
-        const int sample = wbase + (j < jfull ? 16 * (j >> 2) + (j & 3) + 4 * g : 4 * jfull + (j - jfull) + (J - jfull) * g);
-#pragma unroll
-        for (int u = 0; u < NB; ++u) op[set][u] = *reinterpret_cast<const float*>(slot + fb[u] + sample * fs[u]);
-    };
-    auto products = [&](int set) {
+    const int J = JT ? JT : a.T >> 5, wbase = (a.T >> 3) * wave, jfull = J & ~3;
+    auto products = [&](const float (&op)[NB]) {
         int k = 0;
 #pragma unroll
         for (int b1 = 0; b1 < NB; ++b1)
 #pragma unroll
             for (int b2 = b1; b2 < NB; ++b2, ++k)
-                acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(op[set][b1], op[set][b2], acc[k], 0, 0, 0);
+                acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(op[b1], op[b2], acc[k], 0, 0, 0);
     };
-    fetch(0, 0);
-    for (int j = 0; j < J; j += 2) {
-        if (j + 1 < J) fetch(1, j + 1);
-        __builtin_amdgcn_sched_barrier(0);                 // the reads of step j + 1 are issued before the MFMAs of step j
-        products(0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (j + 1 < J) {
-            if (j + 2 < J) fetch(0, j + 2);
+    if constexpr (JT > 0) {
+        // per-lane address of every feature's operand, advanced from k-step to k-step by adds only: + one sample inside a run of
+        // four steps, + 13 samples from one run to the next, the short last run from its own base
+        constexpr int JF = JT & ~3;
+        int cur[NB], fs13[NB], tail[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            cur[u] = fb[u] + (wbase + 4 * g) * fs[u]; fs13[u] = 13 * fs[u];
+            tail[u] = fb[u] + (wbase + 4 * JF + (JT - JF) * g) * fs[u];
+        }
+        float op[JT][NB];
+        auto fetch = [&](int j) {                              // called for j = 0, 1, 2, ... in order
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                if (j == JF) cur[u] = tail[u];
+                op[j][u] = *reinterpret_cast<const float*>(smem + cur[u]);
+                cur[u] += (j < JF && (j & 3) == 3) ? fs13[u] : fs[u];
+            }
+        };
+        fetch(0);
+        if (JT > 1) fetch(1);
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            if (j + 2 < JT) fetch(j + 2);                      // operands two k-steps ahead
+            hook(j);
             __builtin_amdgcn_sched_barrier(0);
-            products(1);
+            products(op[j]);
             __builtin_amdgcn_sched_barrier(0);
         }
-    }
-    lin_barrier();                                         // every wave has read its last operand: the slot turns into scratch
-    float* scr = reinterpret_cast<float*>(slot);           // [wave][block][lane][4]: 16-byte lane-linear writes
+    } else {
+        // Operands run one step ahead in a second register set, and the scheduler is told to keep it that way: left alone hipcc
+        // reuses one register set and waits out the full LDS latency before every MFMA.
+        float op[2][NB];
+        auto fetch = [&](int set, int j) {
+            const int sample = wbase + (j < jfull ? 16 * (j >> 2) + (j & 3) + 4 * g : 4 * jfull + (j - jfull) + (J - jfull) * g);
 #pragma unroll
-    for (int k = 0; k < NBLK; ++k) *reinterpret_cast<f32x4*>(scr + ((wave * NBLK + k) * 64 + lane) * 4) = acc[k];
+            for (int u = 0; u < NB; ++u) op[set][u] = *reinterpret_cast<const float*>(smem + fb[u] + sample * fs[u]);
+        };
+        fetch(0, 0);
+        for (int j = 0; j < J; j += 2) {
+            if (j + 1 < J) fetch(1, j + 1);
+            hook(j);
+            __builtin_amdgcn_sched_barrier(0);                 // the reads of step j + 1 are issued before the MFMAs of step j
+            products(op[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + 1 < J) {
+                if (j + 2 < J) fetch(0, j + 2);
+                hook(j + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                products(op[1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+// The eight per-wave images are summed through LDS (in wave order: deterministic) in `scratch` -- the tile's own slot, dead once
+// every wave has passed the barrier behind its products -- and leave as ONE image in the accumulators' own layout
+// [block][lane][4] (image element (row, col) of a block sits at ((row >> 2) * 16 + col) * 4 + (row & 3): lin_img_index), so the
+// sum reads and the store are 16 bytes per lane.
+template <int NB, bool SC1>
+__device__ __forceinline__ void lin_tile_combine(const f32x4 (&acc)[NB * (NB + 1) / 2], char* scratch, float* out, int t, int wave, int lane) {
+    constexpr int NBLK = NB * (NB + 1) / 2;
+    f32x4* scr = reinterpret_cast<f32x4*>(scratch);       // [wave][block][lane]
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) scr[(wave * NBLK + k) * 64 + lane] = acc[k];
     lin_barrier();
-    for (int o = t; o < NBLK * 256; o += LNT) {            // image element (row, col) of block k <- lane (row / 4) * 16 + col, register row % 4
-        const int k = o >> 8, row = (o >> 4) & 15, col = o & 15, src = ((k * 64 + (row >> 2) * 16 + col) << 2) + (row & 3);
-        float sum = 0.f;
+    for (int q = t; q < NBLK * 64; q += LNT) {
+        f32x4 sum = scr[q];
 #pragma unroll
-        for (int w = 0; w < LNW; ++w) sum += scr[w * NBLK * 256 + src];
-        if (SC1) st_sc1(out + o, sum); else out[o] = sum;
+        for (int w = 1; w < LNW; ++w) sum += scr[w * NBLK * 64 + q];
+        if (SC1) st_sc1_x4(out + 4 * q, sum); else *reinterpret_cast<f32x4*>(out + 4 * q) = sum;
     }
+}
+// (block, row, col) of image element e in that layout
+__device__ __forceinline__ void lin_img_coords(int e, int& blk, int& i, int& j) {
+    blk = e >> 8; const int ln = (e >> 2) & 63; i = ((ln >> 4) << 2) + (e & 3); j = ln & 15;
 }
 
 // ---- reducer: 32 outputs x 16 row groups per workgroup, float64, fixed order ------------------------------------------------
@@ -441,7 +555,8 @@ struct LinUpd {
     template <bool SC1>
     __device__ __forceinline__ void expand_M(const double* M_in) {
         for (int e = threadIdx.x; e < NBLK * 256; e += LNT) {
-            const int k = e >> 8, i = (e >> 4) & 15, j = e & 15;
+            int k, i, j;
+            lin_img_coords(e, k, i, j);
             int b1 = 0, rem = k;
             while (rem >= NB - b1) { rem -= NB - b1; ++b1; }
             const int b2 = b1 + rem;
@@ -461,7 +576,8 @@ struct LinUpd {
         for (int k = 0; k < MPT; ++k) {
             const int e = threadIdx.x + LNT * k;
             if (e < NBLK * 256) {
-                const int blk = e >> 8, i = (e >> 4) & 15, j = e & 15;
+                int blk, i, j;
+                lin_img_coords(e, blk, i, j);
                 int b1 = 0, rem = blk;
                 while (rem >= NB - b1) { rem -= NB - b1; ++b1; }
                 const int b2 = b1 + rem;
@@ -674,6 +790,288 @@ struct LinUpd {
     }
 };
 
+// ---- updater on the float64 matrix cores (persistent form; D <= 16, L <= 32, L + 2 D + 1 <= 48) ------------------------------------
+// The same algebra as LinUpd, laid out so that the dependent chain SM -> P1 -> G never leaves the registers: with the FEATURE index
+// on the MFMA column (lane & 15) every product is  Out = Weights x Prev  and an accumulator tile of v_mfma_f64_16x16x4_f64
+// (lane (col, g), register r = row g + 4 r) is exactly the B operand of the next product's k-step r in natural k order (probed
+// with exact integers: tools/mfma_f64_probe.hip; 64 cycles per instruction, dependent or not).  Wave w < 3 owns feature block w:
+//     SM[:, blk]  = diag(s) M[z1 rows, blk] + be (x) M[one, blk]  (accumulator init)  +  We^T . M[x rows, blk]        (2 row tiles x KD k-steps)
+//     P1[:, blk]  = -M[x rows] + sigma M[z2 rows] + bd (x) M[one]  (init)              +  Wd^T . SM                     (4 + RL1 k-steps)
+//     G[:, blk]   =                                                                       Wd . P1                       (2 x KD)
+// and every gradient that is an ELEMENT of those tiles is finished in place: dWe / dbe = c0 G + (SM - s M[z1 row]) / B on the x and
+// "one" columns, d lv on the diagonal of the z1 columns, dbd = c0 P1[:, one].  Only dWd = S P1^T sums over the feature index, i.e.
+// across lanes: the chain waves drop P1 (4.6 KB) into LDS and wave 3 forms dwd^T = P1[:, x cols] We + ... with 2 x KD MFMAs while
+// the chain waves run G.  The four scalar sums are wave reductions of values the lanes hold anyway.  Per step: 3 barriers,
+// ~17 dependent MFMAs (1.1 k cycles) instead of ~7 k cycles of LDS-bound float64 FMAs.  M arrives straight from the reducers'
+// image into registers (17 write-through loads per lane at offsets fixed for the launch, prefetched a step ahead when the
+// reducers are ahead): no symmetric copy in LDS.
+using d4 = __attribute__((ext_vector_type(4))) double;
+__device__ __forceinline__ double lin_wave_sum(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+// element (r, c) of the symmetric moment matrix in the packed image (upper block triangle, accumulator layout)
+__device__ __forceinline__ int lin_m_index(int NB, int r, int c) {
+    const int br = r >> 4, bc = c >> 4;
+    const int b1 = br <= bc ? br : bc, b2 = br <= bc ? bc : br, i = br <= bc ? (r & 15) : (c & 15), j = br <= bc ? (c & 15) : (r & 15);
+    return lin_blk(NB, b1, b2) * 256 + (((i >> 2) * 16 + j) << 2) + (i & 3);
+}
+template <int NB, int DT, int LT>
+struct LinUpdM {
+    static constexpr int NFP = 16 * NB;
+    static constexpr int KD = DT ? (DT + 3) / 4 : 4;                                   // k-steps over the data dimension
+    static constexpr int RL1 = LT ? (LT > 16 ? (LT - 16 + 3) / 4 : 0) : 4;             // registers of the second latent row tile that can hold a row
+    static constexpr int NM = 4 + RL1 + 2 * KD + 1;                                    // M values per chain lane
+    int D, L, P, fone, off_be, off_wd, off_bd, off_epsp, off_eps;
+    double *Wed, *Wdd, *bed, *bdd, *sd, *elv, *lvd, *scal, *part, *P1s, *gq;
+    float p[LKOUT], m[LKOUT], v[LKOUT];
+    int mo[NM];                                                                        // chain lanes: image offsets of their M values
+
+    static __host__ __device__ constexpr bool shape_ok(int D, int L) { return D <= 16 && L <= 32 && L + 2 * D + 1 <= NFP && NB == 3; }
+    static __host__ size_t lds_bytes(int D, int L, int P) {
+        return sizeof(double) * ((size_t)2 * D * L + 4 * L + D + 8 + 16 + 16 * NFP + (size_t)(P + kExtra + 7));
+    }
+    __device__ __forceinline__ void carve(const LinArgs& a, char* smem) {
+        D = DT ? DT : a.D; L = LT ? LT : a.L; P = a.P; fone = L + 2 * D; off_eps = a.off_eps;
+        off_be = D * L; off_wd = off_be + L; off_bd = off_wd + L * D; off_epsp = off_bd + D;
+        Wed = reinterpret_cast<double*>(smem); Wdd = Wed + D * L; bed = Wdd + L * D; bdd = bed + L; sd = bdd + D; elv = sd + L; lvd = elv + L;
+        scal = lvd + L; part = scal + 8; P1s = part + 16; gq = P1s + 16 * NFP;
+    }
+    __device__ __forceinline__ void load_state(const LinArgs& a) {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < LKOUT; ++k) {
+            const int idx = min(t + LNT * k, P - 1);
+            p[k] = a.params[idx]; m[k] = a.m[idx]; v[k] = a.v[idx];
+        }
+        if (off_eps < 0 && t == 0) { const double e = (double)a.eps_cli, sg = exp(0.5 * e); scal[0] = e; scal[1] = sg; scal[2] = 1.0 / (sg * sg); }
+        // image offsets of this lane's M values (chain waves: wave w = feature block w)
+        const int lane = t & 63, j = lane & 15, g = lane >> 4, f = min(16 * (t >> 6) + j, NFP - 1);
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mo[k++] = lin_m_index(NB, g + 4 * r, f);                                   // z1 rows 0 .. 15
+#pragma unroll
+        for (int r = 0; r < RL1; ++r) mo[k++] = lin_m_index(NB, min(16 + g + 4 * r, NFP - 1), f);             // z1 rows 16 ..
+#pragma unroll
+        for (int r = 0; r < KD; ++r) mo[k++] = lin_m_index(NB, min(L + g + 4 * r, NFP - 1), f);               // x rows
+#pragma unroll
+        for (int r = 0; r < KD; ++r) mo[k++] = lin_m_index(NB, min(L + D + g + 4 * r, NFP - 1), f);           // z2 rows
+        mo[k++] = lin_m_index(NB, fone, f);
+    }
+    __device__ __forceinline__ void fetch_M(const double* M_in, double (&r)[NM]) const {
+#pragma unroll
+        for (int k = 0; k < NM; ++k) r[k] = ld_sc1(M_in + mo[k]);
+    }
+    // float64 copies of this thread's own parameters into the arrays the products read
+    __device__ __forceinline__ void publish_params(const LinArgs& a) {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < LKOUT; ++k) {
+            const int i = t + LNT * k;
+            const double pv = (double)p[k];
+            if (i < off_be) Wed[i] = pv;
+            else if (i < off_wd) bed[i - off_be] = pv;
+            else if (i < off_bd) Wdd[i - off_wd] = pv;
+            else if (i < off_epsp) bdd[i - off_bd] = pv;
+            else if (i < off_epsp + L) { const double sl = exp(0.5 * pv); sd[i - off_epsp] = sl; elv[i - off_epsp] = sl * sl; lvd[i - off_epsp] = pv; }
+            else if (i == off_eps) { const double e = pv * (double)a.eps_cli, sg = exp(0.5 * e); scal[0] = e; scal[1] = sg; scal[2] = 1.0 / (sg * sg); }
+        }
+    }
+    // one step.  In: parameters published and a barrier behind them; mreg = this lane's values of the batch's M (chain waves).
+    // Out: p / m / v updated, gout[] this thread's gradients.  Ends WITHOUT a barrier: the caller's next publish_params writes arrays
+    // that only the phases before this step's last barrier read.
+    // next_cnt / M_next: the NEXT batch's reducer counter and M (nullptr: none); if its reducers are done already, its M is loaded
+    // into mnext under this step's second half and have_next says so.
+    __device__ __forceinline__ void step(const LinArgs& a, int tstep, const double (&mreg)[NM], float (&gout)[LKOUT], const unsigned* next_cnt,
+                                         unsigned per_set, const double* M_next, double (&mnext)[NM], bool& have_next) {
+        const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, j = lane & 15, g = lane >> 4;
+        LIN_STAMP(1);
+        if (t == 64 * (NB + 2)) scal[4] = (next_cnt && __hip_atomic_load(next_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= per_set) ? 1.0 : 0.0;
+        const double eps = scal[0], sigma = scal[1], inv_var = scal[2], inv_bt = (double)a.inv_bt, c0 = inv_var * inv_bt;
+        d4 sm[2], p1;
+        double sl[2][4], bl[2][4];
+        double musq_p = 0.0, ssq_p = 0.0, z2r_p = 0.0;
+        const int f = 16 * wave + j;                                   // chain waves: this lane's feature column
+        if (wave < NB) {
+            const double* Mz = mreg; const double* Mx = mreg + 4 + RL1; const double* Mz2 = Mx + KD; const double Mone = mreg[NM - 1];
+            // ---- SM ----
+#pragma unroll
+            for (int lt = 0; lt < 2; ++lt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int l = 16 * lt + g + 4 * r;
+                    const bool ok = l < L && (lt == 0 || r < RL1);
+                    sl[lt][r] = ok ? sd[min(l, L - 1)] : 0.0; bl[lt][r] = ok ? bed[min(l, L - 1)] : 0.0;
+                    sm[lt][r] = (lt == 0 || r < RL1) ? sl[lt][r] * Mz[lt == 0 ? r : min(4 + r, 3 + RL1)] + bl[lt][r] * Mone : 0.0;
+                }
+#pragma unroll
+            for (int kk = 0; kk < KD; ++kk) {
+                const int dd = 4 * kk + g;
+#pragma unroll
+                for (int lt = 0; lt < 2; ++lt) {
+                    if (lt == 1 && RL1 == 0) continue;
+                    const int l = 16 * lt + j;
+                    const double aw = (dd < D && l < L) ? Wed[min(dd, D - 1) * L + min(l, L - 1)] : 0.0;
+                    sm[lt] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, Mx[kk], sm[lt], 0, 0, 0);
+                }
+            }
+            // ---- P1 ----
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = g + 4 * r;
+                p1[r] = (r < KD && d < D) ? -Mx[min(r, KD - 1)] + sigma * Mz2[min(r, KD - 1)] + bdd[min(d, D - 1)] * Mone : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int l = 4 * r + g;
+                const double aw = (j < D && l < L) ? Wdd[min(l, L - 1) * D + min(j, D - 1)] : 0.0;
+                p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, sm[0][r], p1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < RL1; ++r) {
+                const int l = 16 + 4 * r + g;
+                const double aw = (j < D && l < L) ? Wdd[min(l, L - 1) * D + min(j, D - 1)] : 0.0;
+                p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, sm[1][r], p1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P1s[(g + 4 * r) * NFP + f] = p1[r];
+        } else if (wave == NB + 1) {
+            // 1 + lv - e^{lv} summed over the latent dimension (the closed-form KL term of the loss)
+            const double kl = lane < L ? 1.0 + lvd[min(lane, L - 1)] - elv[min(lane, L - 1)] : 0.0;
+            const double tot = lin_wave_sum(kl);
+            if (lane == 0) part[12] = tot;
+        }
+        LIN_STAMP(2);
+        __syncthreads();                                               // P1 is in LDS
+        LIN_STAMP(3);
+        have_next = scal[4] != 0.0;
+        if (wave < NB) {
+            if (have_next) fetch_M(M_next, mnext);
+            // ---- G = Wd P1 ----
+            d4 G[2];
+            G[0] = d4{0.0, 0.0, 0.0, 0.0}; G[1] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < KD; ++r) {
+                const int d = 4 * r + g;
+#pragma unroll
+                for (int lt = 0; lt < 2; ++lt) {
+                    if (lt == 1 && RL1 == 0) continue;
+                    const int l = 16 * lt + j;
+                    const double aw = (l < L && d < D) ? Wdd[min(l, L - 1) * D + min(d, D - 1)] : 0.0;
+                    G[lt] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, p1[r], G[lt], 0, 0, 0);
+                }
+            }
+            // ---- the gradients that are elements of these tiles ----
+            const double* Mz = mreg;
+            const bool is_x = f >= L && f < L + D, is_z2 = f >= L + D && f < fone, is_one = f == fone, is_z1 = f < L;
+            if (is_x || is_one) {
+                const int base = is_x ? (f - L) * L : off_be;          // dWe[dd][:] resp. dbe
+#pragma unroll
+                for (int lt = 0; lt < 2; ++lt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (lt == 1 && r >= RL1) continue;
+                        const int l = 16 * lt + g + 4 * r;
+                        if (l < L) {
+                            const double q = sm[lt][r] - sl[lt][r] * Mz[lt == 0 ? r : min(4 + r, 3 + RL1)];           // Q = E M
+                            gq[base + l] = c0 * G[lt][r] + q * inv_bt;
+                            musq_p += (is_x ? Wed[base + l] : bl[lt][r]) * q;
+                        }
+                    }
+            }
+            if (is_one) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int d = g + 4 * r;
+                    if (d < D) { gq[off_bd + d] = c0 * p1[r]; ssq_p += bdd[d] * p1[r]; }
+                }
+            }
+            if (is_z1 && (j & 3) == g) {                               // the lane that holds G[f][f]
+                const int lt = f >> 4, r = j >> 2;
+                double gll = 0.0;
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                    for (int r2 = 0; r2 < 4; ++r2) gll = (q2 == lt && r2 == r) ? G[q2][r2] : gll;
+                gq[off_epsp + f] = 0.5 * sd[f] * c0 * gll - 0.5 * (1.0 - elv[f]) * (double)a.rows_over_bt;
+            }
+            if (is_x || is_z2) {                                       // the diagonal entries P1[d][x_d], P1[d][z2_d] of the residual sums
+                const int d = is_x ? f - L : f - L - D;
+                if ((d & 3) == g) {
+                    double pd = 0.0;
+#pragma unroll
+                    for (int r2 = 0; r2 < 4; ++r2) pd = (r2 == (d >> 2)) ? p1[r2] : pd;
+                    if (is_x) ssq_p -= pd; else { ssq_p += sigma * pd; z2r_p += pd; }
+                }
+            }
+            musq_p = lin_wave_sum(musq_p); ssq_p = lin_wave_sum(ssq_p); z2r_p = lin_wave_sum(z2r_p);
+            if (lane == 0) { part[3 * wave] = ssq_p; part[3 * wave + 1] = musq_p; part[3 * wave + 2] = z2r_p; }
+        } else if (wave == NB) {
+            // ---- dwd^T[d][l] = s_l P1[d][l] + be_l P1[d][one] + sum_dd P1[d][x_dd] We[dd][l]  (rows d = g + 4 r, columns l = 16 ct + j) ----
+            d4 C[2];
+            double wsum = 0.0;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                if (ct == 1 && RL1 == 0) continue;
+                const int l = 16 * ct + j, lc = min(l, L - 1);
+                const double s_l = l < L ? sd[lc] : 0.0, b_l = l < L ? bed[lc] : 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) C[ct][r] = s_l * P1s[(g + 4 * r) * NFP + lc] + b_l * P1s[(g + 4 * r) * NFP + fone];
+#pragma unroll
+                for (int kk = 0; kk < KD; ++kk) {
+                    const int dd = 4 * kk + g;
+                    const double av = P1s[j * NFP + min(L + dd, NFP - 1)];
+                    const double bv = (dd < D && l < L) ? Wed[min(dd, D - 1) * L + lc] : 0.0;
+                    C[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, C[ct], 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int d = g + 4 * r;
+                    if (l < L && d < D) { gq[off_wd + l * D + d] = c0 * C[ct][r]; wsum += Wdd[l * D + d] * C[ct][r]; }
+                }
+            }
+            wsum = lin_wave_sum(wsum);
+            if (lane == 0) part[9] = wsum;
+        }
+        LIN_STAMP(4);
+        __syncthreads();                                               // every gradient and partial sum is in LDS
+        LIN_STAMP(5);
+        const double rows = (double)a.rows;
+        const float bc1 = -expm1f((float)tstep * -0.10536051565782628f), bc2 = -expm1f((float)tstep * -0.0010005003335835335f);
+#pragma unroll
+        for (int k = 0; k < LKOUT; ++k) {
+            const int idx = t + LNT * k;
+            double gd = 0.0;
+            if (idx < P && idx != off_eps) gd = gq[idx];
+            else if (idx == off_eps || (idx >= P && idx < P + 3)) {
+                const double ssq = part[0] + part[3] + part[6] + part[9], musq = part[1] + part[4] + part[7], z2r = part[2] + part[5] + part[8], klc = part[12];
+                if (idx == off_eps) gd = (double)a.eps_cli * (-0.5 * ssq * inv_var + 0.5 * rows * D + 0.5 * sigma * z2r * inv_var) * inv_bt;
+                else {
+                    const double dkl = (0.5 * musq - 0.5 * rows * klc) * inv_bt;
+                    const double mse = (0.5 * ssq * inv_var + 0.5 * rows * D * ((double)kLog2Pi + eps)) * inv_bt;
+                    gd = idx == P ? dkl + mse : (idx == P + 1 ? dkl : mse);
+                }
+            }
+            const float gf = (float)gd;
+            gout[k] = gf;
+            if (idx == P && a.loss_hist) a.loss_hist[(long long)(tstep - 1) % a.loss_hist_cap] = gf;
+            if (idx < P) adam_apply_f(p[k], gf, m[k], v[k], a.lr, bc1, bc2);
+        }
+        LIN_STAMP(6);
+    }
+    __device__ __forceinline__ void store_state(const LinArgs& a, const float (&gout)[LKOUT], int tstep) {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < LKOUT; ++k) {
+            const int idx = t + LNT * k;
+            if (idx < P + kExtra) a.grads[idx] = gout[k];
+            if (idx < P) { a.params[idx] = p[k]; a.m[idx] = m[k]; a.v[idx] = v[k]; }
+        }
+        if (t == 0) a.step_dev[0] = tstep;
+    }
+};
+
 // ---- launch-per-step form ---------------------------------------------------------------------------------------------------------
 template <int NB, int DT, int LT>
 __global__ __launch_bounds__(LNT) void lin_step_kernel(const LinArgs a) {
@@ -697,67 +1095,66 @@ __global__ __launch_bounds__(LNT) void lin_step_kernel(const LinArgs a) {
         lin_reduce<false>(a.partial_in, a.M_out, a.ntiles, lin_smem, b - a.has_update, NO);
     } else {
         const int tile = b - a.has_update - a.n_reduce;
-        const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-        const LinSlot sl(a.D, a.L, a.T);
-        lin_issue_tile(a, sl, a.x, a.z1, a.z2, tile, lin_smem, t, wave);
+        const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+        const LinTile tl(a.D, a.L, a.T);
+        const int stride = max(tl.bytes, lin_scratch_bytes(NB)), v_off = stride, c_off = v_off + 4 * a.T;
+        for (int p = wave; p < tl.np; p += LNW) lin_issue_piece(a, tl, a.x, a.z1, a.z2, tile, p, lin_smem, lane);
+        lin_write_vcol(reinterpret_cast<float*>(lin_smem + v_off), a.T, (int)min((long long)a.T, (long long)a.B - (long long)tile * a.T), t);
+        if (t == 0) *reinterpret_cast<float*>(lin_smem + c_off) = 0.f;
         lin_wait_vmcnt<0>();
-        __syncthreads();
-        lin_fix_tile(a, sl, a.x, a.z1, a.z2, tile, lin_smem, t);
-        lin_multiply_tile<NB, false>(a, sl, lin_smem, a.partial_out + (long long)tile * NO, t, wave);
+        lin_barrier();
+        lin_fix_ragged(a, tl, a.x, a.z1, a.z2, tile, lin_smem, t);
+        f32x4 acc[NB * (NB + 1) / 2];
+        lin_tile_products<NB, 0>(a, tl, lin_smem, 0, v_off, c_off, acc, lane, wave, [](int) {});
+        lin_barrier();                                         // every wave has read its last operand: the slot turns into scratch
+        lin_tile_combine<NB, false>(acc, lin_smem, a.partial_out + (long long)tile * NO, t, wave, lane);
     }
 }
 
 // ---- persistent form: up to kLinMaxPersist steps in one launch ----------------------------------------------------------------
-template <int NB, int DT, int LT>
-__global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) {       // one workgroup per CU (its LDS request sees to that)
+template <int NB, int DT, int LT, int JT>
+__global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, const LinPtrs ptrs) {       // one workgroup per CU (its LDS request sees to that)
     extern __shared__ __attribute__((aligned(16))) char lin_smem[];
     const int b = blockIdx.x, t = threadIdx.x, N = a.n_steps;
     constexpr int NO = NB * (NB + 1) / 2 * 256;
     const int per_set = a.n_reduce / a.sets;                  // reducer workgroups per set
     if (b < a.has_update) {
-        // ---- the updater: one workgroup, parameters and Adam state in registers / LDS across all N steps -------------------
-        LinUpd<NB, DT, LT> u;
+        // ---- the updater: one workgroup, parameters and Adam state in registers / LDS across all N steps (the host sends only
+        // shapes the matrix-core updater covers into this form: lin_persist_supported) -------------------------------------------
+        LinUpdM<NB, DT, LT> u;
         u.carve(a, lin_smem);
         int tstep = a.step_dev[0];
         u.load_state(a);
         float g[LKOUT];
 #pragma unroll
         for (int k = 0; k < LKOUT; ++k) g[k] = 0.f;
+        constexpr int NM = LinUpdM<NB, DT, LT>::NM;
+        double mreg[NM], mnext[NM];
+        bool have_next = false;
         LIN_STAMP(10);
-        [[maybe_unused]] unsigned long long tw0 = 0, tw1 = 0, twait = 0, twait_max = 0;
-        double mreg[LinUpd<NB, DT, LT>::MPT];
-        bool pre_ok = false;                                   // (uniform) mreg already holds this batch's M
         for (int n = 0; n < N; ++n) {
             LIN_STAMP(0);
-            u.publish_params();
+            u.publish_params(a);
             LIN_STAMP(9);
-            LIN_NOW(tw0);
-            if (!pre_ok) {
+            if (!have_next) {
                 lin_wait_count(a.cnt_reduce + n, (unsigned)per_set, a.status, (1u << 28) | ((unsigned)n << 16));     // (also the barrier behind publish_params)
-                u.fetch_M(a.M_base + (long long)n * NO, mreg);
+                if (t < 64 * NB) u.fetch_M(a.M_base + (long long)n * NO, mreg);
             } else {
                 __syncthreads();
+#pragma unroll
+                for (int k = 0; k < NM; ++k) mreg[k] = mnext[k];
             }
-            LIN_NOW(tw1);
-            twait += tw1 - tw0; twait_max = tw1 - tw0 > twait_max ? tw1 - tw0 : twait_max;
-            if (n == 0) LIN_PUT(13, tw1 - tw0);
-            LIN_PUT(11, twait); LIN_PUT(12, twait_max);
             LIN_STAMP(8);
-            u.scatter_M(mreg);
-            // are the reducers of the next batch done already?  (they usually are: the streamers run ahead.)  Then its M is loaded
-            // now and travels under this step's arithmetic; otherwise the top of the next iteration waits as usual.
-            if (t == 0)
-                u.epsv[1] = (n + 1 < N && __hip_atomic_load(a.cnt_reduce + n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)per_set) ? 1.0 : 0.0;
-            __syncthreads();
-            pre_ok = u.epsv[1] != 0.0;
-            if (pre_ok) u.fetch_M(a.M_base + (long long)(n + 1) * NO, mreg);
             ++tstep;
-            u.step(a, tstep, g);
-            __syncthreads();                                   // everybody is done reading the LDS copies before they are refreshed
+            u.step(a, tstep, mreg, g, n + 1 < N ? a.cnt_reduce + n + 1 : nullptr, (unsigned)per_set, a.M_base + (long long)(n + 1) * NO, mnext, have_next);
             LIN_STAMP(7);
             { [[maybe_unused]] unsigned long long te = 0; LIN_NOW(te); LIN_PUT(64 + n, te); }
         }
         u.store_state(a, g, tstep);
+        // every reducer has added to the last batch's counter, every streamer long before: nobody reads or writes the arrival
+        // counters any more -- zero them for the next launch (write-through; the kernel boundary orders them)
+        for (int k = t; k < N * kLinShards; k += LNT) __hip_atomic_store(a.cnt_stream + k * kLinShardStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = t; k < N; k += LNT) __hip_atomic_store(a.cnt_reduce + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (b < a.has_update + a.n_reduce) {
         // ---- reducers: set (rb / per_set) takes batches set, set + 2, ... ------------------------------------------------------
         const int rb = b - a.has_update, set = rb / per_set, ro = rb % per_set;
@@ -765,7 +1162,7 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) { 
         [[maybe_unused]] unsigned long long r0 = 0, r1 = 0, r2 = 0, racc_w = 0, racc_r = 0;
         for (int n = set; n < N; n += a.sets) {
             LIN_NOWQ(r0);
-            lin_wait_count(a.cnt_stream + n, (unsigned)a.ntiles, a.status, (2u << 28) | ((unsigned)n << 16));
+            lin_wait_shards(a.cnt_stream + n * kLinShards * kLinShardStride, (unsigned)a.ntiles, a.status, (2u << 28) | ((unsigned)n << 16));
             LIN_NOWQ(r1);
             // 32-output slices, two at a time where there are two (a 128-output form reading 16 bytes per lane with sc1 buffer loads
             // measured 8 % SLOWER per step)
@@ -787,63 +1184,96 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a) { 
             { [[maybe_unused]] unsigned long long te = 0; LIN_NOW(te); LIN_PUTMAX(128 + n, te); }
         }
     } else {
-        // ---- streamers: workgroup sid takes tiles sid, sid + S, ... of every batch, in batch order, through a ring of two LDS
-        // slots: the loads of work item i + 1 are in flight while item i is multiplied.  The batch pointers live in LDS (one
-        // fetch per launch: a scalar load per batch would sit on the critical path with the memory system busy).
+        // ---- streamers: workgroup sid takes tiles sid, sid + S, ... of every batch, in batch order, through a ring of THREE LDS
+        // slots.  Iteration i multiplies item i while the LDS-DMA pieces of item i + 2 are issued between its k-steps (the issue
+        // cost hides behind the matrix pipe) and item i + 1 is in flight.  Per wave the memory operations retire in issue order
+        //     ... P(i) | S(i - 2) | P(i + 1) | S(i - 1) | [iteration i:] P(i + 2) | S(i)        (P: pieces, S: the partial image's store)
+        // so ONE counted wait at the top of iteration i -- all but P(i + 1) and S(i - 1) -- says that tile i has landed and that
+        // this wave's share of image i - 2 has left; the barrier behind it makes both true for the workgroup, and one lane signals
+        // image i - 2.  The batch pointers come in as kernel arguments and live in LDS.
         const int sid = b - a.has_update - a.n_reduce, S = a.n_stream;
         { [[maybe_unused]] unsigned long long te = 0; LIN_NOWQ(te); if (sid == 0) LIN_PUT(50, te); if (sid == S / 2) LIN_PUT(51, te); if (sid == S - 1) LIN_PUT(52, te); }
-        const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-        const LinSlot sl(a.D, a.L, a.T);
-        const int stride = max(sl.bytes, lin_scratch_bytes(NB));        // a slot doubles as the multiply's cross-wave scratch
-        const float** tab = reinterpret_cast<const float**>(lin_smem + 2 * stride);            // [3][kLinMaxPersist]
+        const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+        const LinTile tl(a.D, a.L, a.T);
+        const int stride = max(tl.bytes, lin_scratch_bytes(NB));        // a slot doubles as the combine's cross-wave scratch
+        const int v_off = 3 * stride, vr_off = v_off + 4 * a.T, c_off = vr_off + 4 * a.T;
+        const float** tab = reinterpret_cast<const float**>(lin_smem + c_off + 16);            // [3][kLinMaxPersist]
         if (t < 3 * kLinMaxPersist) {
             const int which = t / kLinMaxPersist, n = t % kLinMaxPersist;
-            tab[t] = n < N ? (which == 0 ? a.xs : which == 1 ? a.z1s : a.z2s)[n] : nullptr;
+            tab[t] = n < N ? (which == 0 ? ptrs.x : which == 1 ? ptrs.z1 : ptrs.z2)[n] : nullptr;
         }
+        const int valid_last = a.B - (a.ntiles - 1) * a.T;              // rows of a batch's last tile
+        lin_write_vcol(reinterpret_cast<float*>(lin_smem + v_off), a.T, a.T, t);
+        lin_write_vcol(reinterpret_cast<float*>(lin_smem + vr_off), a.T, valid_last, t);
+        if (t == 0) *reinterpret_cast<float*>(lin_smem + c_off) = 0.f;
         __syncthreads();
         const int per_batch = sid < a.ntiles ? (a.ntiles - sid + S - 1) / S : 0, items = N * per_batch;
+        const int npw = wave < tl.np ? (tl.np - wave + LNW - 1) / LNW : 0;                      // this wave's pieces of a tile
+        const int sw = wave < (NO / 4 + 63) / 64 ? 1 : 0;                                        // does this wave store a share of an image?
         auto item_batch = [&](int i) { return i / per_batch; };
         auto item_tile = [&](int i) { return sid + (i % per_batch) * S; };
-        auto issue = [&](int i) {
-            const int n = item_batch(i);
-            lin_issue_tile(a, sl, tab[n], tab[kLinMaxPersist + n], tab[2 * kLinMaxPersist + n], item_tile(i), lin_smem + (i & 1) * stride, t, wave);
+        LinTileSrc nxt;                                       // the item whose pieces are being issued
+        auto prepare = [&](int i) {
+            nxt.on = false;
+            if (i < items) {
+                const int n = item_batch(i);
+                nxt.prepare(a, tab[n], tab[kLinMaxPersist + n], tab[2 * kLinMaxPersist + n], item_tile(i), lin_smem + (i % 3) * stride);
+            }
         };
-        if (items > 0) issue(0);
+        auto issue_piece = [&](int k) {                       // k-th piece of this wave's share of that item
+            if (nxt.on && k < npw) nxt.issue(tl, wave + LNW * k, lane);
+        };
+        unsigned* const my_shard = a.cnt_stream + (b & (kLinShards - 1)) * kLinShardStride;
+        auto signal = [&](int i) {                            // image of item i is out (ONE lane, behind every wave's drain + a barrier)
+            if (t == 0) __hip_atomic_fetch_add(my_shard + item_batch(i) * kLinShards * kLinShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        prepare(0);
+        for (int k = 0; k < npw; ++k) issue_piece(k);
+        prepare(1);
+        for (int k = 0; k < npw; ++k) issue_piece(k);
         [[maybe_unused]] unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, sacc_i = 0, sacc_l = 0, sacc_f = 0, sacc_m = 0;
         for (int i = 0; i < items; ++i) {
-            // (the slot item i + 1 lands in was released by the barrier that closed iteration i - 1)
             LIN_NOWQ(s0);
-            if (i + 1 < items) { issue(i + 1); LIN_NOWQ(s1); lin_wait_vmcnt_upto(sl.passes); } else lin_wait_vmcnt<0>();
-            // tile i has landed, and -- the counter retires in order -- so have this wave's write-through stores of item i - 1
-            lin_barrier();
+            lin_wait_vmcnt_upto((i + 1 < items ? npw : 0) + (i >= 1 ? sw : 0));       // tile i has landed, this wave's share of image i - 2 is out
+            LIN_NOWQ(s1);
+            lin_barrier();                                     // ... for every wave; and everybody is done with slot (i + 2) % 3 (the scratch of i - 1)
             LIN_NOWQ(s2);
-            if (i >= 1 && t == 0) __hip_atomic_fetch_add(a.cnt_stream + item_batch(i - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (i == 1) { [[maybe_unused]] unsigned long long te = 0; LIN_NOWQ(te); if (sid == 0) LIN_PUT(53, te); if (sid == S / 2) LIN_PUT(54, te); if (sid == S - 1) LIN_PUT(55, te); }
+            if (i >= 3) signal(i - 2);                         // (image 0 left at the end of iteration 0)
             const int n = item_batch(i), tile = item_tile(i);
-            char* slot = lin_smem + (i & 1) * stride;
-            lin_fix_tile(a, sl, tab[n], tab[kLinMaxPersist + n], tab[2 * kLinMaxPersist + n], tile, slot, t);
+            char* slot = lin_smem + (i % 3) * stride;
+            const bool ragged = tile == a.ntiles - 1 && valid_last < a.T;
+            if (ragged) lin_fix_ragged(a, tl, tab[n], tab[kLinMaxPersist + n], tab[2 * kLinMaxPersist + n], tile, slot, t);
             LIN_NOWQ(s3);
-            lin_multiply_tile<NB, true>(a, sl, slot, a.partial_base + ((long long)n * a.ntiles + tile) * NO, t, wave);
-            lin_barrier();                                     // every wave's products are done: the slot is free for item i + 2
+            f32x4 acc[NB * (NB + 1) / 2];
+            prepare(i + 2);
+            lin_tile_products<NB, JT>(a, tl, lin_smem, (i % 3) * stride, ragged ? vr_off : v_off, c_off, acc, lane, wave,
+                                      [&](int j) { issue_piece(j); });
+            for (int k = (JT ? JT : a.T >> 5); k < npw; ++k) issue_piece(k);                   // (more pieces than k-steps: not at the shapes in use)
+            lin_barrier();                                     // every wave has read its last operand: the slot turns into scratch
+            lin_tile_combine<NB, true>(acc, slot, a.partial_base + ((long long)n * a.ntiles + tile) * NO, t, wave, lane);
+            if (i == 0) {                                      // the launch's first image: out at once (pipeline fill), not two tiles later
+                lin_wait_vmcnt<0>();
+                lin_barrier();
+                signal(0);
+                if (sid == 0) { [[maybe_unused]] unsigned long long te = 0; LIN_NOWQ(te); LIN_PUT(53, te); }
+            }
             LIN_NOWQ(s4);
             if (i + 1 < items) { sacc_i += s1 - s0; sacc_l += s2 - s1; sacc_f += s3 - s2; sacc_m += s4 - s3; }
             if (sid == 7) { LIN_PUT(42, sacc_i); LIN_PUT(43, sacc_l); LIN_PUT(44, sacc_f); LIN_PUT(45, sacc_m); LIN_PUT(46, (unsigned long long)items); }
         }
         lin_wait_vmcnt<0>();
-        __syncthreads();
-        if (items > 0 && t == 0) __hip_atomic_fetch_add(a.cnt_stream + item_batch(items - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lin_barrier();
+        if (items - 2 >= 1) signal(items - 2);
+        if (items - 1 >= 1) signal(items - 1);
     }
 }
 
-// device tables of batch pointers (the persistent kernel reads them; 1.5 KB of kernarg).  The
-// table launch of a persistent launch also zeroes its arrival counters and status word (a kernel of this stream rather
-// than a memset node: it stays an ordinary kernel node when the call is captured into a hipGraph).
-struct LinTable { const float* x[kLinMaxPersist]; const float* z1[kLinMaxPersist]; const float* z2[kLinMaxPersist]; int n; unsigned* zero; };
-__global__ void lin_table_kernel(const LinTable tb, const float** xs, const float** z1s, const float** z2s) {
-    const int i = threadIdx.x;
-    if (i < tb.n) { xs[i] = tb.x[i]; z1s[i] = tb.z1[i]; z2s[i] = tb.z2[i]; }
-    if (tb.zero)
-        for (int k = i; k < 1024; k += 64) tb.zero[k] = 0u;
+// zeroes the arrival counters of a workspace (once per workspace: afterwards every launch leaves them zero) and, unless the
+// workspace carries the mark of an earlier initialisation, the sticky status word
+constexpr unsigned kLinMagic = 0x4c494e33u;
+__global__ void lin_init_kernel(unsigned* cnt, int n_words, unsigned* status) {
+    for (int k = threadIdx.x; k < n_words; k += blockDim.x) cnt[k] = 0u;
+    if (threadIdx.x == 0 && status[1] != kLinMagic) { status[0] = 0u; status[1] = kLinMagic; }
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
@@ -863,39 +1293,42 @@ bool lin_steps_supported(const vaek_ctx* c) {
     if (c->cfg.world == 1) return true;
     return lin_persist_supported(c) && c->comm.ready && c->comm.lin_bytes > 0;
 }
-static size_t lin_ring_bytes(const vaek_ctx* c, int T) {        // the streamers' two tile slots (each doubling as the multiply's scratch) + pointer tables
-    const LinSlot sl(c->D, c->L, T);
-    return 2 * std::max((size_t)sl.bytes, (size_t)lin_scratch_bytes(lin_nb(c))) + 3 * kLinMaxPersist * sizeof(void*) + 64;
+// LDS of a persistent streamer: three tile slots (each doubling as the combine's cross-wave scratch), the two validity columns,
+// the zero word, the batch pointer tables
+static size_t lin_ring_bytes(const vaek_ctx* c, int T) {
+    const LinTile tl(c->D, c->L, T);
+    return 3 * std::max((size_t)tl.bytes, (size_t)lin_scratch_bytes(lin_nb(c))) + 8 * (size_t)T + 16 + 3 * kLinMaxPersist * sizeof(void*) + 64;
 }
+constexpr size_t kLinMaxLds = 160 * 1024;
 // Samples per tile.  256, unless a slightly taller tile lets every streamer of the persistent launch take exactly ONE tile per
 // batch (the metric: 65 536 samples = 228 tiles of 288 on the 231 CUs the updater and the reducers leave).
 static int lin_tile_rows(const vaek_ctx* c) {
     const int smax = c->n_cu - 1 - kLinReduceSets * kLinReduceWgs;
     if (smax < 16 || c->B <= 256 * smax) return 256;
     const int T = 32 * (int)(((long long)c->B + 32ll * smax - 1) / (32ll * smax));
-    const LinSlot sl(c->D, c->L, T);
-    return T <= 512 && sl.passes <= 12 && lin_ring_bytes(c, T) <= 160 * 1024 ? T : 256;
+    const LinTile tl(c->D, c->L, T);
+    return T <= 512 && (tl.np + LNW - 1) / LNW <= 12 && lin_ring_bytes(c, T) <= kLinMaxLds ? T : 256;
 }
 static int lin_ntiles(const vaek_ctx* c) { const int T = lin_tile_rows(c); return (c->B + T - 1) / T; }
-static size_t lin_slot_stride(const vaek_ctx* c) {      // one tile slot, large enough to double as the multiply's cross-wave scratch
-    const LinSlot sl(c->D, c->L, lin_tile_rows(c));
-    return std::max((size_t)sl.bytes, (size_t)lin_scratch_bytes(lin_nb(c)));
+static size_t lin_slot_stride(const vaek_ctx* c) {      // one tile slot, large enough to double as the combine's cross-wave scratch
+    const LinTile tl(c->D, c->L, lin_tile_rows(c));
+    return std::max((size_t)tl.bytes, (size_t)lin_scratch_bytes(lin_nb(c)));
 }
-static size_t lin_lds_need(const vaek_ctx* c) {
+static size_t lin_lds_need(const vaek_ctx* c) {         // launch-per-step form: one slot + validity column + zero word | updater | reducer sums
     const int NB = lin_nb(c), D = c->D, L = c->L;
-    const size_t upd = NB == 3 ? LinUpd<3, 0, 0>::lds_bytes(D, L) : LinUpd<4, 0, 0>::lds_bytes(D, L);
-    return std::max(lin_slot_stride(c), std::max(upd, (size_t)16 * 32 * sizeof(double))) + 64;
+    const size_t upd = std::max(NB == 3 ? LinUpd<3, 0, 0>::lds_bytes(D, L) : LinUpd<4, 0, 0>::lds_bytes(D, L), LinUpdM<3, 0, 0>::lds_bytes(D, L, (int)c->P));
+    return std::max(lin_slot_stride(c) + 4 * (size_t)lin_tile_rows(c) + 16, std::max(upd, (size_t)2 * 16 * 32 * sizeof(double))) + 64;
 }
 // The persistent form gives every workgroup a CU of its own (the updater's float64 chains and the streamers' MFMA loops both
 // lose a factor ~2 when they share one): each workgroup asks for more than half a CU's LDS -- the streamers need it anyway for
-// their ring of two tile slots + the batch pointer tables -- and the grid stays within the CU count.
+// their ring of tile slots -- and the grid stays within the CU count.
 static size_t lin_persist_lds(const vaek_ctx* c) {
     return std::max(std::max(lin_lds_need(c), lin_ring_bytes(c, lin_tile_rows(c))), (size_t)82 * 1024);
 }
 static bool lin_persist_supported(const vaek_ctx* c) {
-    const LinSlot sl(c->D, c->L, lin_tile_rows(c));
-    return lin_steps_shape_ok(c) && lin_nb(c) == 3 && lin_persist_lds(c) <= 160 * 1024 && sl.passes <= 12 &&
-           c->n_cu >= 1 + kLinReduceSets * kLinReduceWgs + 16;
+    const LinTile tl(c->D, c->L, lin_tile_rows(c));
+    return lin_steps_shape_ok(c) && lin_nb(c) == 3 && LinUpdM<3, 0, 0>::shape_ok(c->D, c->L) && lin_persist_lds(c) <= kLinMaxLds &&
+           (tl.np + LNW - 1) / LNW <= 12 && c->n_cu >= 1 + kLinReduceSets * kLinReduceWgs + 16;
 }
 // streamer workgroups of the persistent launch: the CUs the updater and the reducers leave, tiles dealt evenly
 static int lin_persist_streamers(const vaek_ctx* c) {
@@ -904,14 +1337,16 @@ static int lin_persist_streamers(const vaek_ctx* c) {
     return (ntiles + per - 1) / per;
 }
 
-struct LinWs { float* partial; double* M; unsigned* cnt; const float** tab; size_t total; };
+// workspace: [cnt_stream: 64 batches x 8 shards x 128 B][cnt_reduce: 64 words][status word, init mark][M slots][partial image slots]
+constexpr size_t kLinCntStreamBytes = (size_t)kLinMaxPersist * kLinShards * kLinShardStride * 4, kLinCntBytes = kLinCntStreamBytes + 1024, kLinHeadBytes = kLinCntBytes + 256;
+struct LinWs { float* partial; double* M; unsigned* cnt; unsigned* cnt_reduce; unsigned* status; size_t total; };
 static LinWs lin_carve(const vaek_ctx* c, char* base) {
     const size_t no = lin_no(c), ntiles = lin_ntiles(c);
     const int slots = lin_persist_supported(c) ? kLinMaxPersist : 2;
     LinWs w{};
     size_t off = 0;
-    w.cnt = reinterpret_cast<unsigned*>(base + off); off += 4096;                 // cnt_stream[64] | cnt_reduce[64] | status, zeroed by lin_table_kernel
-    w.tab = reinterpret_cast<const float**>(base + off); off += 3 * kLinMaxPersist * sizeof(void*) + 256;
+    w.cnt = reinterpret_cast<unsigned*>(base + off); w.cnt_reduce = reinterpret_cast<unsigned*>(base + kLinCntStreamBytes);
+    w.status = reinterpret_cast<unsigned*>(base + kLinCntBytes); off += kLinHeadBytes;
     w.M = reinterpret_cast<double*>(base + off); off += (size_t)slots * no * sizeof(double) + 256;
     w.partial = reinterpret_cast<float*>(base + off); off += (size_t)slots * ntiles * no * sizeof(float) + 256;
     w.total = (off + 255) / 256 * 256;
@@ -924,7 +1359,6 @@ size_t lin_comm_bytes(const vaek_ctx* c) {
     return (size_t)kLinCommBanks * c->cfg.world * 2 * lin_no(c) * sizeof(unsigned long long);
 }
 
-typedef void (*LinKernel)(const LinArgs);
 static int lin_fill_common(const vaek_ctx* c, LinArgs& a, float* params, float* grads, float* m, float* v, int32_t* step_dev, float lr) {
     a.B = c->B; a.D = c->D; a.L = c->L; a.T = lin_tile_rows(c); a.ntiles = lin_ntiles(c);
     a.params = params; a.grads = grads; a.m = m; a.v = v; a.step_dev = step_dev; a.lr = lr;
@@ -943,32 +1377,45 @@ static int lin_fill_common(const vaek_ctx* c, LinArgs& a, float* params, float* 
     return 0;
 }
 
+// once per (context, workspace): the arrival counters start from zero (every persistent launch leaves them zero again)
+static int lin_ensure_init(vaek_ctx* c, const LinWs& w, void* ws, hipStream_t st) {
+    if (c->lin_ws_inited == ws) return VAEK_OK;
+    hipLaunchKernelGGL(lin_init_kernel, dim3(1), dim3(1024), 0, st, w.cnt, (int)(kLinCntBytes / 4), w.status);
+    VAEK_HIP_CHECK(hipGetLastError());
+    c->lin_ws_inited = ws;
+    return VAEK_OK;
+}
+
 int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v, int32_t* step_dev, const float* const* xs,
                     const float* const* z1s, const float* const* z2s, int n_steps, float lr, void* ws, hipStream_t st) {
     const int NB = lin_nb(c), no = lin_no(c), ntiles = lin_ntiles(c);
     const LinWs w = lin_carve(c, static_cast<char*>(ws) + c->ws_lin);
-    // the metric's shape with its dimensions at compile time; every other linear model on the run-time instantiations
-    const int which = (c->D == 12 && c->L == 20) ? 0 : (NB <= 3 ? 1 : 2);
     static const char* env = getenv("VAEK_LIN_PERSIST");              // diagnostic: 0 forces the launch-per-step form
     const bool persistent = lin_persist_supported(c) && (c->cfg.world > 1 || !(env && atoi(env) == 0));   // data parallel: persistent form only
+    // the metric's shape with its dimensions (and the k-steps per wave of its 288-row tile) at compile time; every other linear
+    // model on the run-time instantiations
+    const int which = (c->D == 12 && c->L == 20 && (!persistent || lin_tile_rows(c) == 288)) ? 0 : (NB <= 3 ? 1 : 2);
     const size_t lds = persistent ? lin_persist_lds(c) : lin_lds_need(c);
-    const LinKernel fn = persistent ? (which == 0 ? lin_persist_kernel<3, 12, 20> : lin_persist_kernel<3, 0, 0>)
-                                    : (which == 0 ? lin_step_kernel<3, 12, 20> : which == 1 ? lin_step_kernel<3, 0, 0> : lin_step_kernel<4, 0, 0>);
-    static thread_local bool attr_set[2][3] = {};
-    if (!attr_set[persistent ? 1 : 0][which]) {
-        VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));   // a cap, not a request
-        attr_set[persistent ? 1 : 0][which] = true;
-    }
+    int dev = 0;
+    VAEK_HIP_CHECK(hipGetDevice(&dev));
+    static thread_local unsigned char attr_set[2][3][64] = {};        // hipFuncSetAttribute is per device
+    const auto set_attr = [&](const void* fn) -> int {
+        unsigned char& done = attr_set[persistent ? 1 : 0][which][dev & 63];
+        if (!done) {
+            VAEK_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinMaxLds));   // a cap, not a request
+            done = 1;
+        }
+        return VAEK_OK;
+    };
     if (persistent) {
+        typedef void (*LinPersist)(const LinArgs, const LinPtrs);
+        const LinPersist fn = which == 0 ? lin_persist_kernel<3, 12, 20, 9> : lin_persist_kernel<3, 0, 0, 0>;
+        if (int rc = set_attr((const void*)fn)) return rc;
+        if (int rc = lin_ensure_init(c, w, ws, st)) return rc;
         for (int s0 = 0; s0 < n_steps; s0 += kLinMaxPersist) {
             const int n = std::min(kLinMaxPersist, n_steps - s0);
-            const float** txs = w.tab; const float** tz1 = w.tab + kLinMaxPersist; const float** tz2 = w.tab + 2 * kLinMaxPersist;
-            {
-                LinTable tb{};
-                tb.n = n; tb.zero = w.cnt;
-                for (int i = 0; i < n; ++i) { tb.x[i] = xs[s0 + i]; tb.z1[i] = z1s[s0 + i]; tb.z2[i] = z2s[s0 + i]; }
-                hipLaunchKernelGGL(lin_table_kernel, dim3(1), dim3(64), 0, st, tb, txs, tz1, tz2);
-            }
+            LinPtrs ptrs{};
+            for (int i = 0; i < n; ++i) { ptrs.x[i] = xs[s0 + i]; ptrs.z1[i] = z1s[s0 + i]; ptrs.z2[i] = z2s[s0 + i]; }
             LinArgs a{};
             lin_fill_common(c, a, params, grads, m, v, step_dev, lr);
             a.persistent = 1; a.n_steps = n;
@@ -977,20 +1424,19 @@ int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v
             static const int proles = getenv("VAEK_LIN_ROLES") ? atoi(getenv("VAEK_LIN_ROLES")) : 7;    // diagnostic (tools/lin_roles.sh)
             if (!(proles & 4)) a.has_update = 0;
             if (!(proles & 2)) { a.has_update = 0; a.n_reduce = 0; }
-            a.xs = txs; a.z1s = tz1; a.z2s = tz2;
+            if (!(proles & 1)) a.n_stream = 0;
+            if (proles != 7) c->lin_ws_inited = nullptr;       // nobody re-zeroes the counters without the updater: start over next call
             a.partial_base = w.partial; a.M_base = w.M;
-            a.cnt_stream = w.cnt; a.cnt_reduce = w.cnt + 256; a.status = w.cnt + 512;
+            a.cnt_stream = w.cnt; a.cnt_reduce = w.cnt_reduce; a.status = w.status;
             ProfScope ps("lin_moments_persistent", st);
-            launch_k(ps, fn, dim3((unsigned)(a.has_update + a.n_reduce + a.n_stream)), dim3(LNT), lds, st, a);
+            launch_k(ps, fn, dim3((unsigned)(a.has_update + a.n_reduce + a.n_stream)), dim3(LNT), lds, st, a, ptrs);
         }
         VAEK_HIP_CHECK(hipGetLastError());
         return VAEK_OK;
     }
-    {   // no in-launch waits in this form: the status word reads "never gave up"
-        LinTable tb{};
-        tb.zero = w.cnt;
-        hipLaunchKernelGGL(lin_table_kernel, dim3(1), dim3(64), 0, st, tb, w.tab, w.tab + kLinMaxPersist, w.tab + 2 * kLinMaxPersist);
-    }
+    typedef void (*LinKernel)(const LinArgs);
+    const LinKernel fn = which == 0 ? lin_step_kernel<3, 12, 20> : which == 1 ? lin_step_kernel<3, 0, 0> : lin_step_kernel<4, 0, 0>;
+    if (int rc = set_attr((const void*)fn)) return rc;
     static const int roles = getenv("VAEK_LIN_ROLES") ? atoi(getenv("VAEK_LIN_ROLES")) : 7;   // diagnostic: 1 stream, 2 reduce, 4 update
     const size_t pstride = (size_t)ntiles * no;
     for (int n = 0; n < n_steps + 2; ++n) {       // launch n: stream batch n, reduce batch n - 1, update batch n - 2
@@ -1011,13 +1457,20 @@ int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v
 }
 
 // synchronous: did a bounded wait of the persistent form ever give up (a workgroup that never became resident, a lost store)?
+// The word is STICKY -- no launch clears it, and while it is set every wait of every later launch returns at once (the grid
+// drains, its results are garbage) -- until this call reads it: read-and-clear.
 int lin_steps_status(vaek_ctx* c, void* ws, int* gave_up) {
     *gave_up = 0;
     if (!lin_steps_shape_ok(c)) return VAEK_OK;
     const LinWs w = lin_carve(c, static_cast<char*>(ws) + c->ws_lin);
+    if (c->lin_ws_inited != ws) return VAEK_OK;            // no persistent launch has used this workspace yet
     unsigned s = 0;
-    VAEK_HIP_CHECK(hipMemcpy(&s, w.cnt + 512, sizeof(s), hipMemcpyDeviceToHost));
+    VAEK_HIP_CHECK(hipMemcpy(&s, w.status, sizeof(s), hipMemcpyDeviceToHost));
     *gave_up = (int)s;
+    if (s) {
+        VAEK_HIP_CHECK(hipMemset(w.status, 0, sizeof(unsigned)));
+        c->lin_ws_inited = nullptr;                        // the counters of the launch that gave up are in an unknown state
+    }
     return VAEK_OK;
 }
 

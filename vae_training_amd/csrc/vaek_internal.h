@@ -111,6 +111,7 @@ struct vaek_ctx {
     unsigned long long* dbg_stamps = nullptr;   // diagnostic builds (-DVAEK_STAMPS) only
     float* loss_hist = nullptr;                 // optional device ring: loss of Adam step t -> [(t-1) % cap]
     int64_t loss_hist_cap = 0;
+    void* lin_ws_inited = nullptr;              // workspace whose vaek_train_steps arrival counters have been zeroed (linear_moments.hip)
 };
 
 namespace vaek {
