@@ -240,6 +240,19 @@ int vaek_train_steps(vaek_ctx* ctx, float* params, float* grads, float* m, float
  * (the results of that call are then invalid).  The word says which wait: 0x80000000 | role << 28 (1 the updater, 2 a reducer)
  * | batch index within the launch << 16 | the arrival count it last saw. */
 int vaek_train_steps_status(vaek_ctx* ctx, void* workspace, int32_t* gave_up);
+/* The same N train steps with the batches DRAWN inside the launch: step k of the call (the one that takes *step_dev from t to
+ * t + 1) trains on the batch vaek_make_batch(kind, A, dd, did, pad, var_added, rows = ctx.batch, row0, seed, step = t, tag)
+ * would write -- the same Philox4x32-10 counters, Box-Muller and dataset maps (csrc/rng_dev.h), bit for bit -- but the batch
+ * never exists in HBM: the streamers of the persistent launch draw each tile straight into LDS between the products of an
+ * earlier tile.  This is the loop body of the reference, model.py:221-222 (dataset.get_batch -> vae.py:123-130 sample_latent,
+ * VAE.train_step), N times per launch.  kind: 0 linear_gaussian, 2 sphere (a linear VAE on the sigmoid dataset has two decoders:
+ * not covered).  Data parallel: every rank passes its own row0 (global row indices).  Capturable into a hipGraph (the RNG step
+ * is the device-resident Adam counter).  vaek_supports_train_steps_gen says whether this context / dataset kind qualifies;
+ * status as vaek_train_steps. */
+int vaek_supports_train_steps_gen(const vaek_ctx* ctx, int32_t kind, int32_t* yes);
+int vaek_train_steps_gen(vaek_ctx* ctx, float* params, float* grads, float* m, float* v, int32_t* step_dev, int32_t kind, const float* A,
+                         int32_t dd, int32_t did, int32_t pad, float var_added, int64_t row0, uint64_t seed, uint32_t tag, int32_t n_steps,
+                         float lr, void* workspace, void* stream);
 /* Convolutional VAE of BASELINE config 5 -- NO reference counterpart (the reference has no convolutional model: its only image
  * code is utils.py:129-133); the layer is specified in DESIGN.md 3.4 and checked against oracle/conv_vae_oracle.py:conv_fwd.
  * 4 x 4 / stride 2 / pad 1 convolution, NHWC float32 tensors, HWIO kernel [4][4][c_in][c_out], bf16 matrix-core products with

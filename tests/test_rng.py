@@ -94,8 +94,8 @@ def test_graph_loop_equals_eager_steps(tmp_path):
                         encoder_layer_sizes="", state_dict=None, data_fn=None, epsilon=-1.0, tqdm=False, dataset=ds,
                         latent_dimension=20, tunable_decoder_var=True, dataset_name="linear_gaussian")
     a, b, c = build(), build(), build()
-    la, lb = GraphLoop(a, steps_per_graph=8, seed=5), GraphLoop(b, steps_per_graph=8, seed=5, pipeline=False)
-    lc = GraphLoop(c, steps_per_graph=8, seed=5, pipeline=False)
+    la, lb = GraphLoop(a, steps_per_graph=8, seed=5, moments=False), GraphLoop(b, steps_per_graph=8, seed=5, pipeline=False, moments=False)
+    lc = GraphLoop(c, steps_per_graph=8, seed=5, pipeline=False, moments=False)
     assert la.pipeline and len(la.bufs) == 2 and len(lb.bufs) == 1
     la.run(31)                       # pipelined: 2 eager warm-ups + 3 replays of 8 + 5 eager
     la.run(12)                       # odd step count so far: one eager step to regain buffer parity, a replay, 3 eager

@@ -71,6 +71,9 @@ SIGNATURES = {
     "vaek_supports_train_steps": (C.c_int, [_vp, C.POINTER(_i32)]),
     "vaek_train_steps": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp]),
     "vaek_train_steps_status": (C.c_int, [_vp, _vp, C.POINTER(_i32)]),
+    "vaek_supports_train_steps_gen": (C.c_int, [_vp, _i32, C.POINTER(_i32)]),
+    "vaek_train_steps_gen": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, C.c_int64, C.c_uint64, C.c_uint32, _i32,
+                                       _f32, _vp, _vp]),
     "vaek_conv2d_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "vaek_to_bf16": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "vaek_conv2d_forward_workspace": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_size_t)]),

@@ -745,6 +745,32 @@ int vaek_train_steps(vaek_ctx* ctx, float* params, float* grads, float* m, float
     return lin_train_steps(ctx, params, grads, m, v, step_dev, xs, z1s, z2s, n_steps, lr, workspace, (hipStream_t)stream);
 }
 
+int vaek_supports_train_steps_gen(const vaek_ctx* ctx, int32_t kind, int32_t* yes) {
+    if (!ctx || !yes) { set_error("null argument"); return VAEK_ERR_INVALID; }
+    *yes = lin_steps_gen_supported(ctx, kind) ? 1 : 0;
+    return VAEK_OK;
+}
+
+int vaek_train_steps_gen(vaek_ctx* ctx, float* params, float* grads, float* m, float* v, int32_t* step_dev, int32_t kind, const float* A,
+                         int32_t dd, int32_t did, int32_t pad, float var_added, int64_t row0, uint64_t seed, uint32_t tag, int32_t n_steps,
+                         float lr, void* workspace, void* stream) {
+    ProfBind pb(ctx);
+    if (!ctx || !params || !grads || !m || !v || !step_dev || n_steps < 0) { set_error("vaek_train_steps_gen: invalid argument"); return VAEK_ERR_INVALID; }
+    if (!lin_steps_gen_supported(ctx, kind)) {
+        set_error("vaek_train_steps_gen: needs a context vaek_train_steps' persistent form covers and dataset kind 0 or 2 (use vaek_train_step_gen)");
+        return VAEK_ERR_INVALID;
+    }
+    int rc = check_ws(ctx, workspace);
+    if (rc) return rc;
+    BatchArgs gen;
+    // (the generator's own output pointers stay unused: a dummy non-null x / z pair passes its argument check)
+    float* dummy = reinterpret_cast<float*>(workspace);
+    if ((rc = make_batch_args(ctx, kind, A, dd, did, pad, var_added, dummy, dummy, dummy, ctx->B, row0, seed, step_dev, 0, nullptr, 0, tag, &gen))) return rc;
+    gen.x = gen.z1 = gen.z2 = nullptr;
+    if (n_steps == 0) return VAEK_OK;
+    return lin_train_steps_gen(ctx, params, grads, m, v, step_dev, gen, n_steps, lr, workspace, (hipStream_t)stream);
+}
+
 int vaek_train_steps_status(vaek_ctx* ctx, void* workspace, int32_t* gave_up) {
     if (!ctx || !workspace || !gave_up) { set_error("null argument"); return VAEK_ERR_INVALID; }
     int g = 0;

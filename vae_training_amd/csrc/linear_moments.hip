@@ -39,7 +39,10 @@
 // different summation order, so this path is NOT bitwise comparable with vaek_train_step.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "comm_dev.h"
+#include "rng_dev.h"
 #include "vaek_internal.h"
 
 namespace vaek {
@@ -1112,8 +1115,13 @@ __global__ __launch_bounds__(LNT) void lin_step_kernel(const LinArgs a) {
 }
 
 // ---- persistent form: up to kLinMaxPersist steps in one launch ----------------------------------------------------------------
-template <int NB, int DT, int LT, int JT>
-__global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, const LinPtrs ptrs) {       // one workgroup per CU (its LDS request sees to that)
+// GEN: the batches are not read from HBM but DRAWN by the streamers, tile by tile, straight into the LDS slots: the Philox work
+// items of vaek_make_batch (rng_dev.h: same counters, same functions, same bits) for the rows of a tile, dealt to the 512
+// threads and issued between the k-steps of an earlier tile exactly where the other form issues its LDS-DMA pieces -- the loop
+// body of model.py:221-222 (get_batch, sample_latent, train_step) with no batch ever in HBM.  The RNG step of the batch that
+// takes the Adam counter from t to t + 1 is t, as in trainer.GraphLoop / vaek_train_step_gen.
+template <int NB, int DT, int LT, int JT, bool GEN>
+__global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, const std::conditional_t<GEN, BatchArgs, LinPtrs> src) {       // one workgroup per CU (its LDS request sees to that)
     extern __shared__ __attribute__((aligned(16))) char lin_smem[];
     const int b = blockIdx.x, t = threadIdx.x, N = a.n_steps;
     constexpr int NO = NB * (NB + 1) / 2 * 256;
@@ -1198,9 +1206,11 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
         const int stride = max(tl.bytes, lin_scratch_bytes(NB));        // a slot doubles as the combine's cross-wave scratch
         const int v_off = 3 * stride, vr_off = v_off + 4 * a.T, c_off = vr_off + 4 * a.T;
         const float** tab = reinterpret_cast<const float**>(lin_smem + c_off + 16);            // [3][kLinMaxPersist]
-        if (t < 3 * kLinMaxPersist) {
-            const int which = t / kLinMaxPersist, n = t % kLinMaxPersist;
-            tab[t] = n < N ? (which == 0 ? ptrs.x : which == 1 ? ptrs.z1 : ptrs.z2)[n] : nullptr;
+        if constexpr (!GEN) {
+            if (t < 3 * kLinMaxPersist) {
+                const int which = t / kLinMaxPersist, n = t % kLinMaxPersist;
+                tab[t] = n < N ? (which == 0 ? src.x : which == 1 ? src.z1 : src.z2)[n] : nullptr;
+            }
         }
         const int valid_last = a.B - (a.ntiles - 1) * a.T;              // rows of a batch's last tile
         lin_write_vcol(reinterpret_cast<float*>(lin_smem + v_off), a.T, a.T, t);
@@ -1208,20 +1218,71 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
         if (t == 0) *reinterpret_cast<float*>(lin_smem + c_off) = 0.f;
         __syncthreads();
         const int per_batch = sid < a.ntiles ? (a.ntiles - sid + S - 1) / S : 0, items = N * per_batch;
-        const int npw = wave < tl.np ? (tl.np - wave + LNW - 1) / LNW : 0;                      // this wave's pieces of a tile
+        const int npw = GEN ? 0 : (wave < tl.np ? (tl.np - wave + LNW - 1) / LNW : 0);          // this wave's pieces of a tile
         const int sw = wave < (NO / 4 + 63) / 64 ? 1 : 0;                                        // does this wave store a share of an image?
         auto item_batch = [&](int i) { return i / per_batch; };
         auto item_tile = [&](int i) { return sid + (i % per_batch) * S; };
         LinTileSrc nxt;                                       // the item whose pieces are being issued
+        nxt.on = false;
         auto prepare = [&](int i) {
-            nxt.on = false;
-            if (i < items) {
-                const int n = item_batch(i);
-                nxt.prepare(a, tab[n], tab[kLinMaxPersist + n], tab[2 * kLinMaxPersist + n], item_tile(i), lin_smem + (i % 3) * stride);
+            if constexpr (!GEN) {
+                nxt.on = false;
+                if (i < items) {
+                    const int n = item_batch(i);
+                    nxt.prepare(a, tab[n], tab[kLinMaxPersist + n], tab[2 * kLinMaxPersist + n], item_tile(i), lin_smem + (i % 3) * stride);
+                }
             }
         };
         auto issue_piece = [&](int k) {                       // k-th piece of this wave's share of that item
-            if (nxt.on && k < npw) nxt.issue(tl, wave + LNW * k, lane);
+            if constexpr (!GEN) { if (nxt.on && k < npw) nxt.issue(tl, wave + LNW * k, lane); }
+        };
+        // GEN: round k of item i's draw -- work item t + 512 k of the tile: (row, 0) = the row of x, (row, 1 + q) = block q of the row's
+        // latent stream (4 normals: columns 4 q .. of [z1 | z2]); rows past the batch end are written as zeros
+        [[maybe_unused]] const int gD = DT ? DT : a.D, gL = LT ? LT : a.L, per_row = 1 + (gL + gD + 3) / 4;
+        [[maybe_unused]] const int gen_items = a.T * per_row, gen_rounds = (gen_items + LNT - 1) / LNT;
+        [[maybe_unused]] const unsigned step0 = (unsigned)a.step_dev[0];          // (the updater stores the counter at the very end of the launch)
+        auto gen_round = [&](int i, int k) {
+            if constexpr (GEN) {
+                const int w = t + LNT * k;
+                if (i < items && k < gen_rounds && w < gen_items) {
+                    const uint2 key = make_uint2((unsigned)src.seed, (unsigned)(src.seed >> 32));
+                    const int r = w / per_row, q = w - r * per_row;
+                    const long long lrow = (long long)item_tile(i) * a.T + r;
+                    const bool live = lrow < a.B;
+                    const long long grow = src.row0 + lrow;
+                    const unsigned step = step0 + (unsigned)item_batch(i);
+                    char* slot = lin_smem + (i % 3) * stride;
+                    if (q == 0) {
+                        float nrm[16];
+                        if (live) dataset_normals(src, step, grow, key, nrm);
+                        float* xr = reinterpret_cast<float*>(slot + tl.oX) + r * gD;
+                        for (int c0 = 0; c0 < gD; c0 += 4) {
+                            float o[4] = {0.f, 0.f, 0.f, 0.f};
+                            if (live) dataset_cols4(src, step, grow, key, nrm, c0, o);
+                            if (gD % 4 == 0) *reinterpret_cast<f32x4*>(xr + c0) = f32x4{o[0], o[1], o[2], o[3]};
+                            else {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) if (c0 + c < gD) xr[c0 + c] = o[c];
+                            }
+                        }
+                    } else {
+                        float n4[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (live) latent_block(src, step, grow, key, q - 1, n4);
+                        const int c0 = 4 * (q - 1);
+                        float* z1r = reinterpret_cast<float*>(slot) + r * gL;
+                        float* z2r = reinterpret_cast<float*>(slot + tl.oZ2) + r * gD;
+                        if (c0 + 3 < gL && gL % 4 == 0) *reinterpret_cast<f32x4*>(z1r + c0) = f32x4{n4[0], n4[1], n4[2], n4[3]};
+                        else if (c0 >= gL && (c0 - gL) + 3 < gD && gD % 4 == 0 && gL % 4 == 0) *reinterpret_cast<f32x4*>(z2r + (c0 - gL)) = f32x4{n4[0], n4[1], n4[2], n4[3]};
+                        else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                if (c0 + c < gL) z1r[c0 + c] = n4[c];
+                                else if (c0 + c < gL + gD) z2r[c0 + c - gL] = n4[c];
+                            }
+                        }
+                    }
+                }
+            }
         };
         unsigned* const my_shard = a.cnt_stream + (b & (kLinShards - 1)) * kLinShardStride;
         auto signal = [&](int i) {                            // image of item i is out (ONE lane, behind every wave's drain + a barrier)
@@ -1231,6 +1292,9 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
         for (int k = 0; k < npw; ++k) issue_piece(k);
         prepare(1);
         for (int k = 0; k < npw; ++k) issue_piece(k);
+        if constexpr (GEN) {
+            for (int k = 0; k < gen_rounds; ++k) { gen_round(0, k); gen_round(1, k); }
+        }
         [[maybe_unused]] unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, sacc_i = 0, sacc_l = 0, sacc_f = 0, sacc_m = 0;
         for (int i = 0; i < items; ++i) {
             LIN_NOWQ(s0);
@@ -1242,13 +1306,18 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
             const int n = item_batch(i), tile = item_tile(i);
             char* slot = lin_smem + (i % 3) * stride;
             const bool ragged = tile == a.ntiles - 1 && valid_last < a.T;
-            if (ragged) lin_fix_ragged(a, tl, tab[n], tab[kLinMaxPersist + n], tab[2 * kLinMaxPersist + n], tile, slot, t);
+            if constexpr (!GEN) {
+                if (ragged) lin_fix_ragged(a, tl, tab[n], tab[kLinMaxPersist + n], tab[2 * kLinMaxPersist + n], tile, slot, t);
+            }
             LIN_NOWQ(s3);
             f32x4 acc[NB * (NB + 1) / 2];
             prepare(i + 2);
             lin_tile_products<NB, JT>(a, tl, lin_smem, (i % 3) * stride, ragged ? vr_off : v_off, c_off, acc, lane, wave,
-                                      [&](int j) { issue_piece(j); });
+                                      [&](int j) { issue_piece(j); gen_round(i + 2, j); });
             for (int k = (JT ? JT : a.T >> 5); k < npw; ++k) issue_piece(k);                   // (more pieces than k-steps: not at the shapes in use)
+            if constexpr (GEN) {
+                for (int k = (JT ? JT : a.T >> 5); k < gen_rounds; ++k) gen_round(i + 2, k);
+            }
             lin_barrier();                                     // every wave has read its last operand: the slot turns into scratch
             lin_tile_combine<NB, true>(acc, slot, a.partial_base + ((long long)n * a.ntiles + tile) * NO, t, wave, lane);
             if (i == 0) {                                      // the launch's first image: out at once (pipeline fill), not two tiles later
@@ -1379,28 +1448,34 @@ static int lin_fill_common(const vaek_ctx* c, LinArgs& a, float* params, float* 
 
 // once per (context, workspace): the arrival counters start from zero (every persistent launch leaves them zero again)
 static int lin_ensure_init(vaek_ctx* c, const LinWs& w, void* ws, hipStream_t st) {
-    if (c->lin_ws_inited == ws) return VAEK_OK;
+    if (c->lin_ws_inited == ws && !c->lin_ws_reinit) return VAEK_OK;
     hipLaunchKernelGGL(lin_init_kernel, dim3(1), dim3(1024), 0, st, w.cnt, (int)(kLinCntBytes / 4), w.status);
     VAEK_HIP_CHECK(hipGetLastError());
     c->lin_ws_inited = ws;
+    c->lin_ws_reinit = false;
     return VAEK_OK;
 }
 
-int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v, int32_t* step_dev, const float* const* xs,
-                    const float* const* z1s, const float* const* z2s, int n_steps, float lr, void* ws, hipStream_t st) {
+// the in-launch batch generator serves the datasets a linear VAE can be trained on (the sigmoid dataset brings a second decoder)
+bool lin_steps_gen_supported(const vaek_ctx* c, int kind) { return lin_steps_supported(c) && lin_persist_supported(c) && (kind == 0 || kind == 2); }
+
+// gen != nullptr: the batches are drawn inside the launch (xs / z1s / z2s unused)
+static int lin_train_steps_impl(vaek_ctx* c, float* params, float* grads, float* m, float* v, int32_t* step_dev, const float* const* xs,
+                                const float* const* z1s, const float* const* z2s, const BatchArgs* gen, int n_steps, float lr, void* ws, hipStream_t st) {
     const int NB = lin_nb(c), no = lin_no(c), ntiles = lin_ntiles(c);
     const LinWs w = lin_carve(c, static_cast<char*>(ws) + c->ws_lin);
     static const char* env = getenv("VAEK_LIN_PERSIST");              // diagnostic: 0 forces the launch-per-step form
-    const bool persistent = lin_persist_supported(c) && (c->cfg.world > 1 || !(env && atoi(env) == 0));   // data parallel: persistent form only
+    const bool persistent = lin_persist_supported(c) && (gen || c->cfg.world > 1 || !(env && atoi(env) == 0));   // data parallel, in-launch draw: persistent form only
+    if (gen && !persistent) { set_error("vaek_train_steps_gen: this context has no persistent form"); return VAEK_ERR_INVALID; }
     // the metric's shape with its dimensions (and the k-steps per wave of its 288-row tile) at compile time; every other linear
     // model on the run-time instantiations
     const int which = (c->D == 12 && c->L == 20 && (!persistent || lin_tile_rows(c) == 288)) ? 0 : (NB <= 3 ? 1 : 2);
     const size_t lds = persistent ? lin_persist_lds(c) : lin_lds_need(c);
     int dev = 0;
     VAEK_HIP_CHECK(hipGetDevice(&dev));
-    static thread_local unsigned char attr_set[2][3][64] = {};        // hipFuncSetAttribute is per device
+    static thread_local unsigned char attr_set[3][3][64] = {};        // hipFuncSetAttribute is per device
     const auto set_attr = [&](const void* fn) -> int {
-        unsigned char& done = attr_set[persistent ? 1 : 0][which][dev & 63];
+        unsigned char& done = attr_set[persistent ? (gen ? 2 : 1) : 0][which][dev & 63];
         if (!done) {
             VAEK_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinMaxLds));   // a cap, not a request
             done = 1;
@@ -1409,13 +1484,13 @@ int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v
     };
     if (persistent) {
         typedef void (*LinPersist)(const LinArgs, const LinPtrs);
-        const LinPersist fn = which == 0 ? lin_persist_kernel<3, 12, 20, 9> : lin_persist_kernel<3, 0, 0, 0>;
-        if (int rc = set_attr((const void*)fn)) return rc;
+        typedef void (*LinPersistGen)(const LinArgs, const BatchArgs);
+        const LinPersist fn = which == 0 ? lin_persist_kernel<3, 12, 20, 9, false> : lin_persist_kernel<3, 0, 0, 0, false>;
+        const LinPersistGen fng = which == 0 ? lin_persist_kernel<3, 12, 20, 9, true> : lin_persist_kernel<3, 0, 0, 0, true>;
+        if (int rc = set_attr(gen ? (const void*)fng : (const void*)fn)) return rc;
         if (int rc = lin_ensure_init(c, w, ws, st)) return rc;
         for (int s0 = 0; s0 < n_steps; s0 += kLinMaxPersist) {
             const int n = std::min(kLinMaxPersist, n_steps - s0);
-            LinPtrs ptrs{};
-            for (int i = 0; i < n; ++i) { ptrs.x[i] = xs[s0 + i]; ptrs.z1[i] = z1s[s0 + i]; ptrs.z2[i] = z2s[s0 + i]; }
             LinArgs a{};
             lin_fill_common(c, a, params, grads, m, v, step_dev, lr);
             a.persistent = 1; a.n_steps = n;
@@ -1425,11 +1500,19 @@ int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v
             if (!(proles & 4)) a.has_update = 0;
             if (!(proles & 2)) { a.has_update = 0; a.n_reduce = 0; }
             if (!(proles & 1)) a.n_stream = 0;
-            if (proles != 7) c->lin_ws_inited = nullptr;       // nobody re-zeroes the counters without the updater: start over next call
+            if (proles != 7) c->lin_ws_reinit = true;          // nobody re-zeroes the counters without the updater: start over next call
             a.partial_base = w.partial; a.M_base = w.M;
             a.cnt_stream = w.cnt; a.cnt_reduce = w.cnt_reduce; a.status = w.status;
-            ProfScope ps("lin_moments_persistent", st);
-            launch_k(ps, fn, dim3((unsigned)(a.has_update + a.n_reduce + a.n_stream)), dim3(LNT), lds, st, a, ptrs);
+            const dim3 grid((unsigned)(a.has_update + a.n_reduce + a.n_stream));
+            if (gen) {
+                ProfScope ps("lin_moments_persistent_gen", st);
+                launch_k(ps, fng, grid, dim3(LNT), lds, st, a, *gen);
+            } else {
+                LinPtrs ptrs{};
+                for (int i = 0; i < n; ++i) { ptrs.x[i] = xs[s0 + i]; ptrs.z1[i] = z1s[s0 + i]; ptrs.z2[i] = z2s[s0 + i]; }
+                ProfScope ps("lin_moments_persistent", st);
+                launch_k(ps, fn, grid, dim3(LNT), lds, st, a, ptrs);
+            }
         }
         VAEK_HIP_CHECK(hipGetLastError());
         return VAEK_OK;
@@ -1456,6 +1539,15 @@ int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v
     return VAEK_OK;
 }
 
+int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v, int32_t* step_dev, const float* const* xs,
+                    const float* const* z1s, const float* const* z2s, int n_steps, float lr, void* ws, hipStream_t st) {
+    return lin_train_steps_impl(c, params, grads, m, v, step_dev, xs, z1s, z2s, nullptr, n_steps, lr, ws, st);
+}
+int lin_train_steps_gen(vaek_ctx* c, float* params, float* grads, float* m, float* v, int32_t* step_dev, const BatchArgs& gen, int n_steps,
+                        float lr, void* ws, hipStream_t st) {
+    return lin_train_steps_impl(c, params, grads, m, v, step_dev, nullptr, nullptr, nullptr, &gen, n_steps, lr, ws, st);
+}
+
 // synchronous: did a bounded wait of the persistent form ever give up (a workgroup that never became resident, a lost store)?
 // The word is STICKY -- no launch clears it, and while it is set every wait of every later launch returns at once (the grid
 // drains, its results are garbage) -- until this call reads it: read-and-clear.
@@ -1469,7 +1561,7 @@ int lin_steps_status(vaek_ctx* c, void* ws, int* gave_up) {
     *gave_up = (int)s;
     if (s) {
         VAEK_HIP_CHECK(hipMemset(w.status, 0, sizeof(unsigned)));
-        c->lin_ws_inited = nullptr;                        // the counters of the launch that gave up are in an unknown state
+        c->lin_ws_reinit = true;                           // the counters of the launch that gave up are in an unknown state
     }
     return VAEK_OK;
 }

@@ -36,6 +36,62 @@ struct NormalStream {           // sequential normals of one row
 };
 
 
+// The dataset stream of global row `grow` at RNG step `step`: up to 16 normals (blocks 0 .. 3 under tag a.tag), kept in
+// registers -- every index below is static (a runtime-indexed array would live in scratch memory).
+__device__ __forceinline__ void dataset_normals(const BatchArgs& a, unsigned step, long long grow, uint2 key, float (&nrm)[16]) {
+    const int nn = a.kind == 0 ? a.did : a.dd;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float n4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (4 * q < nn) normals4(philox4x32_10(make_uint4((unsigned)grow, (unsigned)q, step, a.tag), key), n4);
+        nrm[4 * q] = n4[0]; nrm[4 * q + 1] = n4[1]; nrm[4 * q + 2] = n4[2]; nrm[4 * q + 3] = n4[3];
+    }
+}
+// columns c0 .. c0 + 3 of that row (datasets.py:183-195 linear_gaussian, :240-249 sigmoid, :75-84 sphere) from its normals
+__device__ __forceinline__ void dataset_cols4(const BatchArgs& a, unsigned step, long long grow, uint2 key, const float (&nrm)[16], int c0, float (&o)[4]) {
+    auto pick = [&](int d) { float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v = (k == d) ? nrm[k] : v;
+        return v; };
+    if (a.kind == 0) {                                       // Y = (A X^T)^T, zero padding, optional noise
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int d = c0 + c;
+            float v = 0.f;
+            if (d < a.dd) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) if (k < a.did) v = fmaf(a.A[d * a.did + k], nrm[k], v);
+            }
+            o[c] = v;
+        }
+        if (a.noise_std > 0.f) {                             // noise normals: blocks (did+3)/4 .. of the same stream
+            float n4[4];
+            normals4(philox4x32_10(make_uint4((unsigned)grow, (unsigned)((a.did + 3) / 4 + c0 / 4), step, a.tag), key), n4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = fmaf(a.noise_std, n4[c], o[c]);
+        }
+    } else if (a.kind == 1) {                                // [z, sigmoid(z.a), 0...]
+        float dot = 0.f;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) if (d < a.dd) dot = fmaf(nrm[d], a.A[d], dot);
+        const float sg = 1.f / (1.f + expf(-dot));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const int d = c0 + c; o[c] = d < a.dd ? pick(d) : (d == a.dd ? sg : 0.f); }
+    } else {                                                 // g / |g|, zero padding
+        float nsq = 0.f;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) if (d < a.dd) nsq = fmaf(nrm[d], nrm[d], nsq);
+        const float inv = 1.f / sqrtf(nsq);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const int d = c0 + c; o[c] = d < a.dd ? pick(d) * inv : 0.f; }
+    }
+}
+// block q (4 normals) of the row's latent stream: the draw of model.py:227 in its column order, normal n of a row is element
+// n & 3 of Philox block n >> 2 under tag + 2^30 (columns [0, L) are z1, [L, L + D) z2: vae.py:127-128)
+__device__ __forceinline__ void latent_block(const BatchArgs& a, unsigned step, long long grow, uint2 key, int q, float (&n)[4]) {
+    normals4(philox4x32_10(make_uint4((unsigned)grow, (unsigned)q, step, a.tag + 0x40000000u), key), n);
+}
+
 // Work items: [0, rows*NXB) = 4 columns of one dataset row each; then rows*NZB items = one Philox block (4
 // normals) of one row's latent stream each, so that
 // consecutive lanes store consecutive 16-byte pieces of z1 / z2 -- the 11.5 MB of a 65 536-row batch
@@ -50,53 +106,9 @@ __device__ __forceinline__ void make_batch_items(const BatchArgs& a, unsigned st
         // cheaper than one thread walking a whole row with strided dword stores (that was the long pole: 256
         // workgroups for 65 536 rows took as long as the 2 048 of the latent draw).
         const int i = (int)(item / nxb), c0 = 4 * (int)(item % nxb);
-        // up to 16 normals of the row's dataset stream, kept in registers: every index below is static
-        // (a runtime-indexed array would live in scratch memory)
-        const int nn = a.kind == 0 ? a.did : a.dd;
-        float nrm[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float n4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (4 * q < nn) normals4(philox4x32_10(make_uint4((unsigned)(a.row0 + i), (unsigned)q, step, a.tag), key), n4);
-            nrm[4 * q] = n4[0]; nrm[4 * q + 1] = n4[1]; nrm[4 * q + 2] = n4[2]; nrm[4 * q + 3] = n4[3];
-        }
-        auto pick = [&](int d) { float v = 0.f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) v = (k == d) ? nrm[k] : v;
-            return v; };
-        float o[4];
-        if (a.kind == 0) {                                       // Y = (A X^T)^T, zero padding, optional noise
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int d = c0 + c;
-                float v = 0.f;
-                if (d < a.dd) {
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) if (k < a.did) v = fmaf(a.A[d * a.did + k], nrm[k], v);
-                }
-                o[c] = v;
-            }
-            if (a.noise_std > 0.f) {                             // noise normals: blocks (did+3)/4 .. of the same stream
-                float n4[4];
-                normals4(philox4x32_10(make_uint4((unsigned)(a.row0 + i), (unsigned)((a.did + 3) / 4 + c0 / 4), step, a.tag), key), n4);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) o[c] = fmaf(a.noise_std, n4[c], o[c]);
-            }
-        } else if (a.kind == 1) {                                // [z, sigmoid(z.a), 0...]
-            float dot = 0.f;
-#pragma unroll
-            for (int d = 0; d < 16; ++d) if (d < a.dd) dot = fmaf(nrm[d], a.A[d], dot);
-            const float sg = 1.f / (1.f + expf(-dot));
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { const int d = c0 + c; o[c] = d < a.dd ? pick(d) : (d == a.dd ? sg : 0.f); }
-        } else {                                                 // g / |g|, zero padding
-            float nsq = 0.f;
-#pragma unroll
-            for (int d = 0; d < 16; ++d) if (d < a.dd) nsq = fmaf(nrm[d], nrm[d], nsq);
-            const float inv = 1.f / sqrtf(nsq);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { const int d = c0 + c; o[c] = d < a.dd ? pick(d) * inv : 0.f; }
-        }
+        float nrm[16], o[4];
+        dataset_normals(a, step, a.row0 + i, key, nrm);
+        dataset_cols4(a, step, a.row0 + i, key, nrm, c0, o);
         float* x = a.x + (long long)i * a.D + c0;
         if (a.D % 4 == 0) {
             *reinterpret_cast<float4*>(x) = make_float4(o[0], o[1], o[2], o[3]);
@@ -114,7 +126,7 @@ __device__ __forceinline__ void make_batch_items(const BatchArgs& a, unsigned st
     if (zi >= (long long)a.rows * nzb) return;
     const int i = (int)(zi / nzb), q = (int)(zi % nzb);
     float n[4];
-    normals4(philox4x32_10(make_uint4((unsigned)(a.row0 + i), (unsigned)q, step, a.tag + 0x40000000u), key), n);
+    latent_block(a, step, a.row0 + i, key, q, n);
     const int c0 = 4 * q;
     float* z1 = a.z1 + (long long)i * a.L;
     float* z2 = a.z2 + (long long)i * a.D;

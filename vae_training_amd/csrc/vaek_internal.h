@@ -111,6 +111,7 @@ struct vaek_ctx {
     unsigned long long* dbg_stamps = nullptr;   // diagnostic builds (-DVAEK_STAMPS) only
     float* loss_hist = nullptr;                 // optional device ring: loss of Adam step t -> [(t-1) % cap]
     int64_t loss_hist_cap = 0;
+    bool lin_ws_reinit = false;                 // ... and must be zeroed again before the next launch (a wait gave up; a diagnostic launch without updater)
     void* lin_ws_inited = nullptr;              // workspace whose vaek_train_steps arrival counters have been zeroed (linear_moments.hip)
 };
 
@@ -293,6 +294,10 @@ size_t lin_steps_workspace_bytes(const vaek_ctx* c);
 int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v, int32_t* step_dev, const float* const* xs,
                     const float* const* z1s, const float* const* z2s, int n_steps, float lr, void* ws, hipStream_t st);
 int lin_steps_status(vaek_ctx* c, void* ws, int* gave_up);
+bool lin_steps_gen_supported(const vaek_ctx* c, int kind);
+struct BatchArgs;
+int lin_train_steps_gen(vaek_ctx* c, float* params, float* grads, float* m, float* v, int32_t* step_dev, const BatchArgs& gen, int n_steps,
+                        float lr, void* ws, hipStream_t st);
 
 // ---- rng.hip ------------------------------------------------------------------------------
 // validates the arguments of vaek_make_batch* and fills `out`

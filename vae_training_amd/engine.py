@@ -138,6 +138,19 @@ class Engine:
         _lib.check(self.lib.vaek_train_steps(self.h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(step_dev), xs, z1s, z2s, n,
                                              float(lr), _ptr(self.workspace), _stream()))
 
+    def supports_train_steps_gen(self, kind):
+        f = C.c_int32()
+        _lib.check(self.lib.vaek_supports_train_steps_gen(self.h, int(kind), C.byref(f)))
+        return bool(f.value)
+
+    def train_steps_gen(self, params, grads, m, v, step_dev, n_steps, lr, kind, A, dd, did, pad, var_added, seed, tag=0, row0=0):
+        """n_steps consecutive train steps whose batches are drawn INSIDE the launch (vaek_train_steps_gen): the batch of the step
+        that takes the Adam counter from t to t + 1 is bit for bit the one make_batch(..., step = t) would write, but it never
+        exists in HBM.  Asynchronous; capturable into a hipGraph."""
+        _lib.check(self.lib.vaek_train_steps_gen(self.h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(step_dev), int(kind), _ptr(A),
+                                                 int(dd), int(did), int(pad), float(var_added), int(row0), int(seed) & (2**64 - 1), int(tag),
+                                                 int(n_steps), float(lr), _ptr(self.workspace), _stream()))
+
     def train_steps_gave_up(self):
         """Synchronous: True if a bounded wait inside vaek_train_steps' persistent launch ever expired."""
         f = C.c_int32()

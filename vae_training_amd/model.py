@@ -209,7 +209,10 @@ class GenerativeModel(Model):
                 it = trange(self.num_batches)
             except ImportError:
                 pass
-        if getattr(self, "fast_loop", False):
+        fast = getattr(self, "fast_loop", False)
+        if fast is None:                 # auto: the models vaek_train_steps_gen covers (linear VAEs) take the loop built on it
+            fast = self._fast_loop_qualifies()
+        if fast:
             return self._train_distribution_fast()
         for self.batchnum in it:
             if self.batchnum % self.n_print == 0:
@@ -222,6 +225,17 @@ class GenerativeModel(Model):
                 self._dp_sync()
             self.train_one_batch(self.dataset.get_batch(self.batch_size))
         self._dp_check()
+
+    def _fast_loop_qualifies(self):
+        try:
+            from .datasets import DEVICE_DRAW_MAX_DIM
+            kind, _, dd, did, _, _ = self.dataset.device_spec()
+            if dd > DEVICE_DRAW_MAX_DIM or did > DEVICE_DRAW_MAX_DIM:
+                return False
+            eng = self.model.module.engine(self.batch_size, self.optimizer.global_batch)
+            return bool(eng.supports_train_steps_gen(kind))
+        except Exception:
+            return False
 
     def _train_distribution_fast(self):
         """Same schedule (stats every n_print, plot+save every n_plot and at the last step), but the steps in
@@ -236,6 +250,7 @@ class GenerativeModel(Model):
             loop.run(ev - pos)
             pos = ev
             self.batchnum = ev
+            loop.check()
             self._dp_check()
             if ev % self.n_print == 0:
                 self.write_stats(self.compute_stats())
@@ -244,6 +259,7 @@ class GenerativeModel(Model):
                 self.save()
                 self._dp_sync()
         loop.run(self.num_batches - pos)
+        loop.check()
         self._dp_check()
 
     def save(self, final=False):

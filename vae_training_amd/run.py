@@ -47,8 +47,12 @@ def build_parser():
     p.add_argument("--comm", default="auto", choices=["auto", "rccl", "p2p"],
                    help="data-parallel gradient exchange: in-kernel peer-to-peer granules (small models) or RCCL all-reduce "
                         "of per-layer buckets overlapped with the backward pass")
-    p.add_argument("--fast_loop", action="store_true",
-                   help="run the steps between stats/plots from a hipGraph with on-device Philox batches (trainer.py)")
+    p.add_argument("--fast_loop", action="store_true", default=None,
+                   help="run the steps between stats/plots with nothing per step on the host (trainer.py): linear VAEs through "
+                        "vaek_train_steps_gen (up to 64 steps per persistent launch, batches drawn inside it), other models from a "
+                        "hipGraph with on-device Philox batches.  Default: on for the models vaek_train_steps_gen covers")
+    p.add_argument("--no_fast_loop", dest="fast_loop", action="store_false",
+                   help="the reference's loop shape: one get_batch + one train_step call per iteration (model.py:221-222)")
     return p
 
 

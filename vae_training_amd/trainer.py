@@ -14,14 +14,21 @@ is ONE launch (10 us per step at the reference's batch size 100).  The draw take
 generator advances itself, not from the Adam step counter that same launch is incrementing.  Same
 counters, same Philox streams: losses and parameters are bit-identical to `pipeline=False`
 (vaek_make_batch, then vaek_train_step).  (A second stream / parallel graph branch for the draw was
-measured first: cross-branch edges of a hipGraph cost far more than the 7 us they were meant to hide.)"""
+measured first: cross-branch edges of a hipGraph cost far more than the 7 us they were meant to hide.)
+
+`moments` (default: whenever the model qualifies -- a linear VAE on the linear_gaussian or sphere dataset): the steps go through
+vaek_train_steps_gen, the headline kernel of bench.py (csrc/linear_moments.hip): up to 64 steps per persistent launch, every
+step's batch drawn INSIDE the launch by the workgroups that multiply it -- the same Philox counters as above, so the same
+batches bit for bit, but no batch buffer, no hipGraph and nothing per step on the host: one library call per run of steps
+between two events of the reference's schedule (stats every 5 000, plot + save every 50 000: model.py:213-220).  The losses land
+in the same device ring.  Losses and parameters agree with the per-sample loop to summation order (tests/test_gpu_loop.py)."""
 from __future__ import annotations
 
 import torch
 
 
 class GraphLoop:
-    def __init__(self, vae_model, steps_per_graph=200, seed=None, loss_capacity=1 << 20, pipeline=True):
+    def __init__(self, vae_model, steps_per_graph=200, seed=None, loss_capacity=1 << 20, pipeline=True, moments=None):
         m = vae_model
         self.m = m
         ds = m.dataset
@@ -33,12 +40,16 @@ class GraphLoop:
         self.B = m.batch_size
         self.eng = m.model.module.engine(self.B, m.optimizer.global_batch)
         ex = m.optimizer.exchange
-        if self.eng.world > 1 and not (ex is not None and ex.in_library):
+        if self.eng.world > 1 and not (ex is not None and ex.in_library) and not self.eng.supports_train_steps_gen(self.kind):
             raise RuntimeError("GraphLoop under data parallelism needs the in-library P2P exchange (GradExchange mode 'p2p'): "
                                "an RCCL all-reduce between the two halves of the step is not captured")
+        can = self.eng.supports_train_steps_gen(self.kind)
+        if moments and not can:
+            raise RuntimeError("GraphLoop(moments=True): vaek_train_steps_gen does not cover this model / dataset")
+        self.moments = can if moments is None else bool(moments)
         self.row0 = self.eng.rank * self.B           # ranks draw disjoint rows of the global batch
         self.seed = (ds.key[0] ^ ds.key[1] ^ m.key[1]) if seed is None else seed
-        self.pipeline = bool(pipeline)
+        self.pipeline = bool(pipeline) and not self.moments
         self.G = int(steps_per_graph)
         if self.pipeline and self.G % 2:
             self.G += 1                              # two batch buffers: a replay must start on the parity it was captured on
@@ -48,7 +59,7 @@ class GraphLoop:
             return (torch.empty(self.B, self.eng.D, dtype=torch.float32, device=dev),
                     torch.empty(self.B, self.eng.L, dtype=torch.float32, device=dev),
                     torch.empty(self.B, self.eng.D, dtype=torch.float32, device=dev))
-        self.bufs = [bufs() for _ in range(2 if self.pipeline else 1)]
+        self.bufs = [] if self.moments else [bufs() for _ in range(2 if self.pipeline else 1)]
         self.loss_ring = torch.zeros(loss_capacity, dtype=torch.float32, device=dev)
         self.eng.set_loss_history(self.loss_ring)
         self.graph = None
@@ -100,6 +111,14 @@ class GraphLoop:
 
     def run(self, n_steps):
         """Exactly n_steps train steps."""
+        if self.moments:
+            if n_steps > 0:
+                st = self.m.optimizer.state
+                self.eng.train_steps_gen(self.m.model.flat, st.grads, st.m, st.v, st.step_dev, n_steps,
+                                         self.m.optimizer.optimizer_def.learning_rate, self.kind, self.A, self.dd, self.did, self.pad,
+                                         self.var, self.seed, tag=0, row0=self.row0)
+                st.step += n_steps
+            return
         done = 0
         if self.graph is None and n_steps >= self.G + 2:
             done += self._capture()
@@ -114,6 +133,15 @@ class GraphLoop:
                 done += self.G
         for _ in range(n_steps - done):
             self._one()
+
+    def check(self):
+        """Synchronous.  The persistent launches of the moments path wait for each other's hand-offs with bounded spins: one that
+        expired has produced garbage -- stop loudly."""
+        if self.moments:
+            torch.cuda.synchronize()
+            if self.eng.train_steps_gave_up():
+                raise RuntimeError(f"a bounded in-launch wait of vaek_train_steps_gen expired (status {self.eng.train_steps_status_word:#x}): "
+                                   "the steps since the last check are invalid")
 
     def losses(self):
         """Losses of all steps run so far in order (device -> host once)."""
