@@ -343,6 +343,13 @@ def main():
                          "entry point whose launches overlap the pass over batch n + 2 with the Adam update of batch n")
     ap.add_argument("--graph", type=int, default=-1,
                     help="steps captured per hipGraph (0 = eager launches; -1 = auto: the largest even size <= 200 dividing --steps)")
+    ap.add_argument("--repeat", type=int, default=20,
+                    help="how many times the timed region of exactly --steps steps is run (each time behind its own Infinity Cache sweep, "
+                         "barrier and synchronize); `value` is the MEDIAN region, min / max ride along")
+    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "direct"],
+                    help="vaek_train_steps only: replay a hipGraph of the K steps, or call the library directly with pre-marshalled "
+                         "arguments (one persistent launch per 64 steps either way; auto = direct: a graph replay costs the host more "
+                         "than the one or two launches it replaces)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -438,6 +445,8 @@ def main():
             cands = [g for g in range(200, 0, -2) if g <= max(args.steps, 2)]      # even: the fresh-input leg alternates two buffers
             gsteps = min(cands, key=lambda g: (args.steps % g, -g))          # fewest eager left-over steps, then the largest
     graph = None
+    # vaek_train_steps needs no graph: ONE library call covers all K steps (a persistent launch per 64 of them)
+    use_plan = use_pipe and args.launch != "graph" and 0 < args.steps <= 4096
     n_warm_eager = max(args.warmup, 3)
     run_group(0, n_warm_eager)
     if use_pipe and dist is not None:
@@ -449,7 +458,9 @@ def main():
         if float(bad.item()) != 0.0:
             use_pipe = False
             run_group(0, n_warm_eager)
-    if gsteps > 0:
+    if use_plan and not use_pipe:           # (the warm-up found an exchange time-out: back on the per-sample step)
+        use_plan = False
+    if gsteps > 0 and not use_plan:
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -461,9 +472,19 @@ def main():
         fence()                             # ranks leave capture at different times: line them up first
         graph.replay()                      # one untimed replay (graph upload)
 
+    plan = None
+    if use_plan:
+        gsteps = args.steps
+        plan = eng.plan_train_steps(params, grads, m, v, step_dev, [batches[k % len(batches)] for k in range(gsteps)], lr)
+        plan()
+
     def run_steps(n):
         done = 0
-        if graph is not None:
+        if plan is not None:
+            while n - done >= gsteps:
+                plan()
+                done += gsteps
+        elif graph is not None:
             while n - done >= gsteps:
                 graph.replay()
                 done += gsteps
@@ -479,16 +500,19 @@ def main():
         mall_sweep.fill_(1.0)
         run_group(len(batches) - 4, 4)
 
-    sweep()
-    fence()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
+    regions = []
+    for _ in range(max(1, args.repeat)):
+        sweep()
+        fence()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        fence()
+        regions.append(time.perf_counter() - t0)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_one_gpu else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor(regions, dtype=torch.float64, device="cpu" if args.rehearse_one_gpu else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                 # per region: the slowest rank's clock
+        regions = [float(x) for x in t.tolist()]
+    elapsed = float(np.median(regions))
     loss = float(grads[eng.P].item())
     assert math.isfinite(loss), "train step produced a non-finite loss"
     if use_pipe:
@@ -501,7 +525,7 @@ def main():
     # the fused forward/backward chain + finalize/Adam), captured and timed the same way -- what `value` was in round 1
     per_sample = None
     if use_pipe and world == 1:
-        gs2 = max(2, min(gsteps if gsteps > 0 else 20, 200))
+        gs2 = max(2, min(gsteps if gsteps > 0 else 20, 192))
         p2, g2, m2, v2 = params.clone(), eng.new_flat(eng.grad_len), m.clone(), v.clone()
         s2 = step_dev.clone()
 
@@ -531,7 +555,9 @@ def main():
         dt = time.perf_counter() - t1
         per_sample = {"entry_point": "vaek_train_step (per-sample forward/backward chain + finalize: two launches per step)",
                       "samples_per_s": B_local * reps * gs2 / dt, "us_per_step": dt / (reps * gs2) * 1e6, "steps": reps * gs2,
-                      "launch": f"hipGraph x{gs2} steps"}
+                      "launch": f"hipGraph x{gs2} steps",
+                      "note": "A/B leg: at most 400 steps, started right behind an Infinity Cache sweep -- colder than a long run of "
+                              "the same kernels (round 1's driver figure for them, 13.3 us, came from the main timed region)"}
 
     # ---- roofline leg: the same steps again with every library launch bracketed by its own begin/end timestamps ----
     roofline = None
@@ -576,21 +602,33 @@ def main():
                     alg = alg_step
                     kernel_s, kernel_name = step_kernels_s, "all launches of a step (layer-by-layer path)"
             achieved = alg / kernel_s / scale
-            traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh)
-            for rnd in ("r02", "r01"):
-                tfile = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{args.workload}.json")
-                if os.path.exists(tfile) and B_local == w["batch"] and args.dtype == "f32":
-                    kern = json.load(open(tfile))["kernels"]
-                    if eng.fused and "traffic_bytes" in kern.get(dom, {}):
+            # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh): a constant read from profiles/, NOT
+            # measured in this run -- taken from the newest round's file that lists the dominant kernel under its current name
+            # (none: null), and labelled with the file it came from
+            traffic, traffic_source = None, None
+            for rnd in ("r03", "r02", "r01"):
+                tfile = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{args.workload}{'_bf16' if args.dtype == 'bf16' else ''}.json")
+                if not (os.path.exists(tfile) and B_local == w["batch"]):
+                    continue
+                meta = json.load(open(tfile))
+                kern = meta["kernels"]
+                if eng.fused:
+                    if dom not in kern:
+                        continue
+                    if "traffic_bytes" in kern[dom]:
                         traffic = kern[dom]["traffic_bytes"]
-                    elif eng.fused and "traffic_bytes_per_step" in kern.get(dom, {}):       # persistent launch: per step x its steps
+                    elif "traffic_bytes_per_step" in kern[dom]:       # persistent launch: per step x its steps
                         traffic = kern[dom]["traffic_bytes_per_step"] * steps_per_launch
-                    elif not eng.fused:
-                        traffic = sum(v.get("traffic_bytes_per_step", 0) for v in kern.values()) or None
-                    if traffic is not None:
-                        break
+                else:
+                    names = " ".join(v.get("rocprof_name", k) for k, v in kern.items())
+                    if any(k.split("<")[0] not in names and k not in kern for k in rep if k.startswith(("gemm", "ts_gemm", "hs_", "sk_"))):
+                        continue            # a kernel of today's step is missing from that file: its total is stale
+                    traffic = sum(v.get("traffic_bytes_per_step", 0) for v in kern.values()) or None
+                if traffic is not None:
+                    traffic_source = f"profiles/{os.path.basename(tfile)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, {meta.get('commit', 'commit not recorded')}; not measured in this run)"
+                    break
             roofline = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
-                        "traffic": traffic, "kernel": kernel_name, "kernel_avg_us": kernel_s * 1e6,
+                        "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_name, "kernel_avg_us": kernel_s * 1e6,
                         "dominant_kernel": dom, "dominant_kernel_avg_us": dom_avg_s * 1e6,
                         "steps_per_dominant_launch": (rsteps / rep[dom]["count"] if dom.startswith("lin_moments") else 1.0),
                         "dominant_kernel_us_per_step": dom_avg_s * 1e6 / (rsteps / rep[dom]["count"] if dom.startswith("lin_moments") else 1.0),
@@ -612,7 +650,29 @@ def main():
     # reference's loop does (dataset.get_batch + sample_latent, model.py:221 / vae.py:125-128): the Philox draw of
     # batch n+1 rides in the finalize launch of step n (vaek_train_step_gen), all inside the hipGraph
     fresh = None
-    if world == 1 and graph is not None and w["dataset"] == "linear_gaussian":
+    kind = {"linear_gaussian": 0, "sigmoid": 1, "sphere": 2}[w["dataset"]]
+    if world == 1 and use_pipe and eng.supports_train_steps_gen(kind):
+        # the loop body of model.py:221-222 as run.py --fast_loop runs it (trainer.GraphLoop): vaek_train_steps_gen, every step's
+        # batch drawn inside the persistent launch (same Philox streams as vaek_make_batch), nothing read from HBM, no graph
+        A = torch.randn(w["dd"], w["did"], generator=torch.Generator().manual_seed(2)).to(device).contiguous() if kind == 0 else None
+        p3, g3, m3, v3, s3 = params.clone(), eng.new_flat(eng.grad_len), m.clone(), v.clone(), step_dev.clone()
+        gen = lambda n: eng.train_steps_gen(p3, g3, m3, v3, s3, n, lr, kind, A, w["dd"], w["did"], w["pad"], 0.0, 7)
+        gen(64)
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(max(1, min(args.repeat, 10))):
+            t1 = time.perf_counter()
+            gen(args.steps)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t1)
+        dt = float(np.median(times))
+        assert not eng.train_steps_gave_up()
+        fresh = {"samples_per_s": B_local * args.steps / dt, "us_per_step": dt / args.steps * 1e6, "steps": args.steps,
+                 "entry_point": "vaek_train_steps_gen (trainer.GraphLoop, run.py --fast_loop)",
+                 "note": "inputs drawn inside the persistent launch each step (Philox work items in the streamer workgroups, tile by "
+                         "tile into LDS) instead of pre-resident batches: what the reference's loop does per iteration "
+                         "(dataset.get_batch + sample_latent + train_step)"}
+    elif world == 1 and graph is not None and w["dataset"] == "linear_gaussian":
         A = torch.randn(w["dd"], w["did"], generator=torch.Generator().manual_seed(2)).to(device).contiguous()
         assert gsteps % 2 == 0
         bufs = [tuple(torch.empty_like(t) for t in batches[0]) for _ in range(2)]
@@ -659,12 +719,16 @@ def main():
             "metric": "ELBO train-step samples/sec", "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "timed_regions": {"count": len(regions), "steps_each": args.steps, "median_ms_per_step": elapsed / args.steps * 1e3,
+                              "min_ms_per_step": min(regions) / args.steps * 1e3, "max_ms_per_step": max(regions) / args.steps * 1e3,
+                              "note": "value = the median region; each region = exactly --steps train steps between barrier + synchronize"},
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w['desc']}", "batch_per_gpu": B_local, "global_batch": B_global,
                        "data_dim": D, "latent_dim": L, "params": eng.P, "path": "fused" if eng.fused else "layer-by-layer",
                        "step_entry_point": ("vaek_train_steps (up to 64 steps per persistent launch: streamers | reducers | updater)" if use_pipe else "vaek_train_step"),
                        "parallelism": f"dp{world}", "grad_exchange": (exch.mode if exch else "none"),
-                       "launch": (f"hipGraph x{gsteps} steps" if graph is not None else "eager"), "input_batches": nbuf,
+                       "launch": (f"direct library call x{gsteps} steps (arguments marshalled once)" if plan is not None else
+                                  f"hipGraph x{gsteps} steps" if graph is not None else "eager"), "input_batches": nbuf,
                        "final_loss": loss},
             "roofline": roofline, "cpu_baseline": cpu, "per_sample_path": per_sample, "fresh_inputs_each_step": fresh,
         }

@@ -809,10 +809,37 @@ struct LinUpd {
 // image into registers (17 write-through loads per lane at offsets fixed for the launch, prefetched a step ahead when the
 // reducers are ahead): no symmetric copy in LDS.
 using d4 = __attribute__((ext_vector_type(4))) double;
+// Sum over the wave, the same value in every lane.  Four DPP stages inside each row of 16 lanes (the two dwords of a double move
+// separately; xor 1, xor 2, half mirror, mirror: every lane ends with its row's total), then the four rows by v_readlane -- ~25
+// instructions where six __shfl_xor stages are twelve ds_bpermute round trips (the three sums of a step cost 1.8 k cycles that way).
+template <int CTRL>
+__device__ __forceinline__ double lin_dpp_add(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+    return x + __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double lin_wave_sum(double x) {
+    x = lin_dpp_add<0xB1>(x);          // quad_perm [1, 0, 3, 2]
+    x = lin_dpp_add<0x4E>(x);          // quad_perm [2, 3, 0, 1]
+    x = lin_dpp_add<0x141>(x);         // row_half_mirror
+    x = lin_dpp_add<0x140>(x);         // row_mirror
+    double tot = 0.0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-    return x;
+    for (int r = 0; r < 4; ++r)
+        tot += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 16 * r), __builtin_amdgcn_readlane(__double2loint(x), 16 * r));
+    return tot;
+}
+// e^x in float64 (|x| < 700): k = round(x / ln 2), degree-13 Taylor polynomial on |r| <= ln 2 / 2 (truncation 5e-18), one ldexp.
+// ~20 fused multiply-adds on the updater's critical path instead of the library routine's ~3x that.
+__device__ __forceinline__ double lin_exp(double x) {
+    const double k = rint(x * 1.4426950408889634);
+    double r = fma(-k, 6.93147180369123816490e-01, x);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0); p = fma(p, r, 1.0 / 39916800.0); p = fma(p, r, 1.0 / 3628800.0); p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0); p = fma(p, r, 1.0 / 5040.0); p = fma(p, r, 1.0 / 720.0); p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0); p = fma(p, r, 1.0 / 6.0); p = fma(p, r, 0.5); p = fma(p, r, 1.0); p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
 }
 // element (r, c) of the symmetric moment matrix in the packed image (upper block triangle, accumulator layout)
 __device__ __forceinline__ int lin_m_index(int NB, int r, int c) {
@@ -848,7 +875,7 @@ struct LinUpdM {
             const int idx = min(t + LNT * k, P - 1);
             p[k] = a.params[idx]; m[k] = a.m[idx]; v[k] = a.v[idx];
         }
-        if (off_eps < 0 && t == 0) { const double e = (double)a.eps_cli, sg = exp(0.5 * e); scal[0] = e; scal[1] = sg; scal[2] = 1.0 / (sg * sg); }
+        if (off_eps < 0 && t == 0) { const double e = (double)a.eps_cli; scal[0] = e; scal[1] = lin_exp(0.5 * e); scal[2] = lin_exp(-e); }
         // image offsets of this lane's M values (chain waves: wave w = feature block w)
         const int lane = t & 63, j = lane & 15, g = lane >> 4, f = min(16 * (t >> 6) + j, NFP - 1);
         int k = 0;
@@ -877,8 +904,13 @@ struct LinUpdM {
             else if (i < off_wd) bed[i - off_be] = pv;
             else if (i < off_bd) Wdd[i - off_wd] = pv;
             else if (i < off_epsp) bdd[i - off_bd] = pv;
-            else if (i < off_epsp + L) { const double sl = exp(0.5 * pv); sd[i - off_epsp] = sl; elv[i - off_epsp] = sl * sl; lvd[i - off_epsp] = pv; }
-            else if (i == off_eps) { const double e = pv * (double)a.eps_cli, sg = exp(0.5 * e); scal[0] = e; scal[1] = sg; scal[2] = 1.0 / (sg * sg); }
+            else if (i < off_epsp + L || i == off_eps) {
+                // e^{lv / 2} and e^{eps / 2}, e^{-eps}: the same instruction stream for the latent lanes and the epsilon lane
+                const bool is_eps = i == off_eps;
+                const double e = is_eps ? pv * (double)a.eps_cli : pv, h = lin_exp(0.5 * e);
+                if (is_eps) { scal[0] = e; scal[1] = h; scal[2] = lin_exp(-e); }
+                else { sd[i - off_epsp] = h; elv[i - off_epsp] = h * h; lvd[i - off_epsp] = pv; }
+            }
         }
     }
     // one step.  In: parameters published and a barrier behind them; mreg = this lane's values of the batch's M (chain waves).
@@ -943,7 +975,11 @@ struct LinUpdM {
             // 1 + lv - e^{lv} summed over the latent dimension (the closed-form KL term of the loss)
             const double kl = lane < L ? 1.0 + lvd[min(lane, L - 1)] - elv[min(lane, L - 1)] : 0.0;
             const double tot = lin_wave_sum(kl);
-            if (lane == 0) part[12] = tot;
+            if (lane == 0) {
+                part[12] = tot;
+                // Adam's bias corrections 1 - beta^t for everybody (float, as the other paths compute them)
+                part[13] = (double)(-expm1f((float)tstep * -0.10536051565782628f)); part[14] = (double)(-expm1f((float)tstep * -0.0010005003335835335f));
+            }
         }
         LIN_STAMP(2);
         __syncthreads();                                               // P1 is in LDS
@@ -1041,10 +1077,11 @@ struct LinUpdM {
         __syncthreads();                                               // every gradient and partial sum is in LDS
         LIN_STAMP(5);
         const double rows = (double)a.rows;
-        const float bc1 = -expm1f((float)tstep * -0.10536051565782628f), bc2 = -expm1f((float)tstep * -0.0010005003335835335f);
+        const float bc1 = (float)part[13], bc2 = (float)part[14];
 #pragma unroll
         for (int k = 0; k < LKOUT; ++k) {
             const int idx = t + LNT * k;
+            if (LNT * k >= P + 3) break;                               // (uniform) nothing lives up here
             double gd = 0.0;
             if (idx < P && idx != off_eps) gd = gq[idx];
             else if (idx == off_eps || (idx >= P && idx < P + 3)) {
@@ -1295,7 +1332,7 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
         if constexpr (GEN) {
             for (int k = 0; k < gen_rounds; ++k) { gen_round(0, k); gen_round(1, k); }
         }
-        [[maybe_unused]] unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, sacc_i = 0, sacc_l = 0, sacc_f = 0, sacc_m = 0;
+        [[maybe_unused]] unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, sacc_i = 0, sacc_l = 0, sacc_f = 0, sacc_m = 0, sacc_p = 0, sacc_b = 0;
         for (int i = 0; i < items; ++i) {
             LIN_NOWQ(s0);
             lin_wait_vmcnt_upto((i + 1 < items ? npw : 0) + (i >= 1 ? sw : 0));       // tile i has landed, this wave's share of image i - 2 is out
@@ -1318,7 +1355,9 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
             if constexpr (GEN) {
                 for (int k = (JT ? JT : a.T >> 5); k < gen_rounds; ++k) gen_round(i + 2, k);
             }
+            LIN_NOWQ(s5);
             lin_barrier();                                     // every wave has read its last operand: the slot turns into scratch
+            LIN_NOWQ(s6);
             lin_tile_combine<NB, true>(acc, slot, a.partial_base + ((long long)n * a.ntiles + tile) * NO, t, wave, lane);
             if (i == 0) {                                      // the launch's first image: out at once (pipeline fill), not two tiles later
                 lin_wait_vmcnt<0>();
@@ -1327,8 +1366,8 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
                 if (sid == 0) { [[maybe_unused]] unsigned long long te = 0; LIN_NOWQ(te); LIN_PUT(53, te); }
             }
             LIN_NOWQ(s4);
-            if (i + 1 < items) { sacc_i += s1 - s0; sacc_l += s2 - s1; sacc_f += s3 - s2; sacc_m += s4 - s3; }
-            if (sid == 7) { LIN_PUT(42, sacc_i); LIN_PUT(43, sacc_l); LIN_PUT(44, sacc_f); LIN_PUT(45, sacc_m); LIN_PUT(46, (unsigned long long)items); }
+            if (i + 1 < items) { sacc_i += s1 - s0; sacc_l += s2 - s1; sacc_f += s3 - s2; sacc_m += s4 - s3; sacc_p += s5 - s3; sacc_b += s6 - s5; }
+            if (sid == 7) { LIN_PUT(42, sacc_i); LIN_PUT(43, sacc_l); LIN_PUT(44, sacc_f); LIN_PUT(45, sacc_m); LIN_PUT(46, (unsigned long long)items); LIN_PUT(47, sacc_p); LIN_PUT(48, sacc_b); }
         }
         lin_wait_vmcnt<0>();
         lin_barrier();

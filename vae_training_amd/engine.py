@@ -151,6 +151,22 @@ class Engine:
                                                  int(dd), int(did), int(pad), float(var_added), int(row0), int(seed) & (2**64 - 1), int(tag),
                                                  int(n_steps), float(lr), _ptr(self.workspace), _stream()))
 
+    def plan_train_steps(self, params, grads, m, v, step_dev, batches, lr):
+        """The same call with its arguments marshalled once: returns a function that issues vaek_train_steps on these buffers
+        again (the pointer arrays, not the data, are frozen) -- for loops that repeat a group of steps, where building three
+        ctypes arrays per call would cost more host time than the launch."""
+        n = len(batches)
+        for b in batches:
+            assert all(t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 for t in b)
+        arr = lambda k: (C.c_void_p * n)(*[C.c_void_p(b[k].data_ptr()) for b in batches])
+        keep = (params, grads, m, v, step_dev, list(batches))                     # the plan keeps its tensors alive
+        args = (self.h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(step_dev), arr(0), arr(1), arr(2), n, C.c_float(lr), _ptr(self.workspace))
+        fn, check = self.lib.vaek_train_steps, _lib.check
+
+        def run(_keep=keep):
+            check(fn(*args, _stream()))
+        return run
+
     def train_steps_gave_up(self):
         """Synchronous: True if a bounded wait inside vaek_train_steps' persistent launch ever expired."""
         f = C.c_int32()
