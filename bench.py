@@ -397,10 +397,16 @@ def main():
     exch = GradExchange(eng, dist, mode=args.comm) if world > 1 else None
     lr = w["lr"]
 
+    # data parallel over RCCL (no P2P communicator): a linear VAE's step goes through its second-moment matrix too, summed by the
+    # collective between vaek_train_steps_moments and vaek_train_steps_update (launch per step)
+    moments_rccl = exch is not None and not exch.in_library and eng.moment_len() > 0 and not args.no_pipeline
+
     def one_step(i):
         x, z1, z2 = batches[i % len(batches)]
         if exch is None or exch.in_library:
             eng.train_step(params, grads, m, v, step_dev, x, z1, z2, lr)
+        elif moments_rccl:
+            exch.moments_step(params, grads, m, v, step_dev, x, z1, z2, lr)
         elif eng.fused:
             eng.grads_only(params, grads, step_dev, x, z1, z2)
             exch.all_reduce(grads)
@@ -725,7 +731,9 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w['desc']}", "batch_per_gpu": B_local, "global_batch": B_global,
                        "data_dim": D, "latent_dim": L, "params": eng.P, "path": "fused" if eng.fused else "layer-by-layer",
-                       "step_entry_point": ("vaek_train_steps (up to 64 steps per persistent launch: streamers | reducers | updater)" if use_pipe else "vaek_train_step"),
+                       "step_entry_point": ("vaek_train_steps (up to 64 steps per persistent launch: streamers | reducers | updater)" if use_pipe else
+                                            "vaek_train_steps_moments + all-reduce of the 12 KB moment matrix + vaek_train_steps_update (launch per step)"
+                                            if moments_rccl else "vaek_train_step"),
                        "parallelism": f"dp{world}", "grad_exchange": (exch.mode if exch else "none"),
                        "launch": (f"direct library call x{gsteps} steps (arguments marshalled once)" if plan is not None else
                                   f"hipGraph x{gsteps} steps" if graph is not None else "eager"), "input_batches": nbuf,

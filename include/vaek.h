@@ -250,6 +250,17 @@ int vaek_train_steps_status(vaek_ctx* ctx, void* workspace, int32_t* gave_up);
  * is the device-resident Adam counter).  vaek_supports_train_steps_gen says whether this context / dataset kind qualifies;
  * status as vaek_train_steps. */
 int vaek_supports_train_steps_gen(const vaek_ctx* ctx, int32_t kind, int32_t* yes);
+/* The two halves of ONE step of vaek_train_steps' launch-per-step form, for data parallelism over a HOST collective (no P2P
+ * communicator needed): the second-moment matrix of a linear VAE's batch is additive over the ranks' row shards -- the loss of
+ * networks.py:97-98 is a batch mean -- so every rank calls vaek_train_steps_moments on its shard (x, z1, z2 of ctx.batch rows ->
+ * M, a float64 image of vaek_train_steps_moment_len doubles), the caller sums M over the ranks (torch.distributed all_reduce:
+ * RCCL / gloo; every rank receives the same bits), and vaek_train_steps_update turns the summed M into loss, gradients and the Adam
+ * update of networks.py:99-101 with the GLOBAL batch as divisor (ctx.global_batch): replicas stay bitwise identical.  With world
+ * == 1 the pair is one train step.  *len == 0: this context is not a linear VAE the moment form covers. */
+int vaek_train_steps_moment_len(const vaek_ctx* ctx, int64_t* len);
+int vaek_train_steps_moments(vaek_ctx* ctx, const float* x, const float* z1, const float* z2, double* M, void* workspace, void* stream);
+int vaek_train_steps_update(vaek_ctx* ctx, float* params, float* grads, float* m, float* v, int32_t* step_dev, const double* M, float lr,
+                            void* workspace, void* stream);
 int vaek_train_steps_gen(vaek_ctx* ctx, float* params, float* grads, float* m, float* v, int32_t* step_dev, int32_t kind, const float* A,
                          int32_t dd, int32_t did, int32_t pad, float var_added, int64_t row0, uint64_t seed, uint32_t tag, int32_t n_steps,
                          float lr, void* workspace, void* stream);

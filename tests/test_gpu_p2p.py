@@ -220,3 +220,60 @@ def test_pipelined_steps_exchange_their_moments_across_ranks(world):
     for rank, lerr, perr, same, bad, tb in res:
         assert tb is None, tb
         assert lerr <= 1e-5 and perr <= 0.02 * 1e-3 * 7 and same and not bad, (rank, lerr, perr, same, bad)
+
+
+def _moments_rccl_worker(rank, world, port, q):
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        from vae_training_amd.engine import Engine
+        from vae_training_amd.parallel import GradExchange, shard_rows
+        cfg = O.Config(12, 20, (), (), -1.0, True, "linear_gaussian")
+        B, lr, steps = 1536, 1e-3, 6
+        rng = np.random.default_rng(0)
+        r32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+        p = {k: r32(v) for k, v in O.init_params(cfg, seed=0).items()}
+        lo, hi = shard_rows(B, world, rank)
+        eng = Engine(hi - lo, 12, 20, (), (), -1.0, True, False, world=world, rank=rank, global_batch=B)
+        ex = GradExchange(eng, dist, mode="rccl")                  # no P2P communicator: the collective carries the moment matrix
+        assert not ex.in_library and not eng.supports_train_steps() and eng.moment_len() == 6 * 256
+        dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda()
+        params = dev(O.flatten(cfg, p)); grads = eng.new_flat(eng.grad_len); m = eng.new_flat(); v = eng.new_flat()
+        step = torch.zeros(1, dtype=torch.int32, device="cuda")
+        st, worst = O.adam_init(p), 0.0
+        for s in range(steps):
+            x = r32(rng.standard_normal((B, 12))); z1, z2 = O.split_latents(r32(rng.standard_normal((B, 32))), 20)
+            p, st, loss_ref = O.train_step(cfg, p, st, x, z1, z2, lr)              # full batch on the oracle
+            ex.moments_step(params, grads, m, v, step, dev(x[lo:hi]), dev(z1[lo:hi]), dev(z2[lo:hi]), lr)
+            worst = max(worst, abs(float(grads[eng.P]) - loss_ref) / abs(loss_ref))
+        perr = float(np.max(np.abs(params.cpu().numpy().astype(np.float64) - O.flatten(cfg, p))))
+        digest = torch.tensor(params.cpu().numpy().view(np.int32).astype(np.int64).sum().reshape(1))
+        allg = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(allg, digest)
+        q.put((rank, worst, perr, all(int(a) == int(allg[0]) for a in allg), int(step.item()) != steps, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, 1.0, 1.0, False, True, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_moment_matrix_summed_by_the_collective_without_p2p(world):
+    """Data parallel WITHOUT the P2P communicator (GradExchange mode "rccl"; gloo here): vaek_train_steps_moments on each shard, one
+    all-reduce of the float64 moment image, vaek_train_steps_update everywhere -- losses and parameters follow the oracle's
+    FULL-batch training (networks.py:87-101), replicas end bitwise identical."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_moments_rccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, lerr, perr, same, bad, tb in res:
+        assert tb is None, tb
+        assert lerr <= 1e-5 and perr <= 0.02 * 1e-3 * 6 and same and not bad, (rank, lerr, perr, same, bad)

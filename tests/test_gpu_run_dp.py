@@ -78,9 +78,11 @@ def test_bench_py_two_ranks_rehearsed_on_one_gpu(comm, port):
     assert out["config"]["global_batch"] == 2 * out["config"]["batch_per_gpu"]
     assert np.isfinite(out["value"]) and out["value"] > 0 and np.isfinite(out["config"]["final_loss"]), out
     assert out["config"]["grad_exchange"] == comm, out["config"]
-    # P2P transport: the moments are exchanged inside the persistent launch; RCCL transport: the per-sample step + all-reduce
-    assert out["config"]["step_entry_point"].startswith("vaek_train_steps" if comm == "p2p" else "vaek_train_step")
+    # either transport runs the step through the batch's second-moment matrix (vaek_train_steps): P2P exchanges it inside the
+    # persistent launch, RCCL all-reduces it between the two halves of a launch-per-step step
+    assert out["config"]["step_entry_point"].startswith("vaek_train_steps")
     assert (comm == "p2p") == ("persistent" in out["config"]["step_entry_point"])
+    assert (comm == "rccl") == ("all-reduce of the 12 KB moment matrix" in out["config"]["step_entry_point"])
 
 
 def test_conv_vae_two_ranks_equal_one_rank_on_the_whole_batch(tmp_path):

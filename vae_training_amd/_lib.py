@@ -72,6 +72,9 @@ SIGNATURES = {
     "vaek_train_steps": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp]),
     "vaek_train_steps_status": (C.c_int, [_vp, _vp, C.POINTER(_i32)]),
     "vaek_supports_train_steps_gen": (C.c_int, [_vp, _i32, C.POINTER(_i32)]),
+    "vaek_train_steps_moment_len": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "vaek_train_steps_moments": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vaek_train_steps_update": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp]),
     "vaek_train_steps_gen": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, C.c_int64, C.c_uint64, C.c_uint32, _i32,
                                        _f32, _vp, _vp]),
     "vaek_conv2d_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),

@@ -771,6 +771,35 @@ int vaek_train_steps_gen(vaek_ctx* ctx, float* params, float* grads, float* m, f
     return lin_train_steps_gen(ctx, params, grads, m, v, step_dev, gen, n_steps, lr, workspace, (hipStream_t)stream);
 }
 
+int vaek_train_steps_moment_len(const vaek_ctx* ctx, int64_t* len) {
+    if (!ctx || !len) { set_error("null argument"); return VAEK_ERR_INVALID; }
+    *len = (int64_t)lin_moment_len(ctx);
+    return VAEK_OK;
+}
+
+int vaek_train_steps_moments(vaek_ctx* ctx, const float* x, const float* z1, const float* z2, double* M, void* workspace, void* stream) {
+    ProfBind pb(ctx);
+    if (!ctx || !x || !z1 || !z2 || !M) { set_error("vaek_train_steps_moments: null argument"); return VAEK_ERR_INVALID; }
+    if (!lin_moments_supported(ctx)) { set_error("vaek_train_steps_moments: not a float32 linear VAE with L + 2 D + 1 <= 64"); return VAEK_ERR_INVALID; }
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(z1) | reinterpret_cast<uintptr_t>(z2)) & 15) {
+        set_error("vaek_train_steps_moments: batch pointers must be 16-byte aligned");
+        return VAEK_ERR_INVALID;
+    }
+    int rc = check_ws(ctx, workspace);
+    if (rc) return rc;
+    return lin_moments(ctx, x, z1, z2, M, workspace, (hipStream_t)stream);
+}
+
+int vaek_train_steps_update(vaek_ctx* ctx, float* params, float* grads, float* m, float* v, int32_t* step_dev, const double* M, float lr,
+                            void* workspace, void* stream) {
+    ProfBind pb(ctx);
+    if (!ctx || !params || !grads || !m || !v || !step_dev || !M) { set_error("vaek_train_steps_update: null argument"); return VAEK_ERR_INVALID; }
+    if (!lin_moments_supported(ctx)) { set_error("vaek_train_steps_update: not a float32 linear VAE with L + 2 D + 1 <= 64"); return VAEK_ERR_INVALID; }
+    int rc = check_ws(ctx, workspace);
+    if (rc) return rc;
+    return lin_update(ctx, params, grads, m, v, step_dev, M, lr, (hipStream_t)stream);
+}
+
 int vaek_train_steps_status(vaek_ctx* ctx, void* workspace, int32_t* gave_up) {
     if (!ctx || !workspace || !gave_up) { set_error("null argument"); return VAEK_ERR_INVALID; }
     int g = 0;

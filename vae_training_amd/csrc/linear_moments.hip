@@ -355,7 +355,7 @@ __device__ __forceinline__ void lin_tile_products(const LinArgs& a, const LinTil
     // s + 4 g in step s: four rows apart, i.e. 16 banks with 80- and 48-byte rows, so the lane groups one ds_read_b32 services
     // together never collide; a run shorter than 16 (T / 8 not a multiple of 16: its last r < 4 steps) takes s + r g.
     const int J = JT ? JT : a.T >> 5, wbase = (a.T >> 3) * wave, jfull = J & ~3;
-    auto products = [&](const float (&op)[NB]) {
+    auto products = [&](const float (&op)[NB]) __attribute__((always_inline)) {
         int k = 0;
 #pragma unroll
         for (int b1 = 0; b1 < NB; ++b1)
@@ -374,7 +374,7 @@ __device__ __forceinline__ void lin_tile_products(const LinArgs& a, const LinTil
             tail[u] = fb[u] + (wbase + 4 * JF + (JT - JF) * g) * fs[u];
         }
         float op[JT][NB];
-        auto fetch = [&](int j) {                              // called for j = 0, 1, 2, ... in order
+        auto fetch = [&](int j) __attribute__((always_inline)) {                              // called for j = 0, 1, 2, ... in order
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
                 if (j == JF) cur[u] = tail[u];
@@ -396,7 +396,7 @@ __device__ __forceinline__ void lin_tile_products(const LinArgs& a, const LinTil
         // Operands run one step ahead in a second register set, and the scheduler is told to keep it that way: left alone hipcc
         // reuses one register set and waits out the full LDS latency before every MFMA.
         float op[2][NB];
-        auto fetch = [&](int set, int j) {
+        auto fetch = [&](int set, int j) __attribute__((always_inline)) {
             const int sample = wbase + (j < jfull ? 16 * (j >> 2) + (j & 3) + 4 * g : 4 * jfull + (j - jfull) + (J - jfull) * g);
 #pragma unroll
             for (int u = 0; u < NB; ++u) op[set][u] = *reinterpret_cast<const float*>(smem + fb[u] + sample * fs[u]);
@@ -1261,7 +1261,7 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
         auto item_tile = [&](int i) { return sid + (i % per_batch) * S; };
         LinTileSrc nxt;                                       // the item whose pieces are being issued
         nxt.on = false;
-        auto prepare = [&](int i) {
+        auto prepare = [&](int i) __attribute__((always_inline)) {
             if constexpr (!GEN) {
                 nxt.on = false;
                 if (i < items) {
@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
                 }
             }
         };
-        auto issue_piece = [&](int k) {                       // k-th piece of this wave's share of that item
+        auto issue_piece = [&](int k) __attribute__((always_inline)) {   // k-th piece of this wave's share of that item
             if constexpr (!GEN) { if (nxt.on && k < npw) nxt.issue(tl, wave + LNW * k, lane); }
         };
         // GEN: round k of item i's draw -- work item t + 512 k of the tile: (row, 0) = the row of x, (row, 1 + q) = block q of the row's
@@ -1278,7 +1278,7 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
         [[maybe_unused]] const int gD = DT ? DT : a.D, gL = LT ? LT : a.L, per_row = 1 + (gL + gD + 3) / 4;
         [[maybe_unused]] const int gen_items = a.T * per_row, gen_rounds = (gen_items + LNT - 1) / LNT;
         [[maybe_unused]] const unsigned step0 = (unsigned)a.step_dev[0];          // (the updater stores the counter at the very end of the launch)
-        auto gen_round = [&](int i, int k) {
+        auto gen_round = [&](int i, int k) __attribute__((always_inline)) {
             if constexpr (GEN) {
                 const int w = t + LNT * k;
                 if (i < items && k < gen_rounds && w < gen_items) {
@@ -1330,7 +1330,8 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
         prepare(1);
         for (int k = 0; k < npw; ++k) issue_piece(k);
         if constexpr (GEN) {
-            for (int k = 0; k < gen_rounds; ++k) { gen_round(0, k); gen_round(1, k); }
+#pragma unroll 1
+            for (int k = 0; k < 2 * gen_rounds; ++k) gen_round(k & 1, k >> 1);
         }
         [[maybe_unused]] unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, sacc_i = 0, sacc_l = 0, sacc_f = 0, sacc_m = 0, sacc_p = 0, sacc_b = 0;
         for (int i = 0; i < items; ++i) {
@@ -1350,9 +1351,10 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
             f32x4 acc[NB * (NB + 1) / 2];
             prepare(i + 2);
             lin_tile_products<NB, JT>(a, tl, lin_smem, (i % 3) * stride, ragged ? vr_off : v_off, c_off, acc, lane, wave,
-                                      [&](int j) { issue_piece(j); gen_round(i + 2, j); });
+                                      [&](int j) __attribute__((always_inline)) { issue_piece(j); gen_round(i + 2, j); });
             for (int k = (JT ? JT : a.T >> 5); k < npw; ++k) issue_piece(k);                   // (more pieces than k-steps: not at the shapes in use)
             if constexpr (GEN) {
+#pragma unroll 1
                 for (int k = (JT ? JT : a.T >> 5); k < gen_rounds; ++k) gen_round(i + 2, k);
             }
             LIN_NOWQ(s5);
@@ -1525,7 +1527,8 @@ static int lin_train_steps_impl(vaek_ctx* c, float* params, float* grads, float*
         typedef void (*LinPersist)(const LinArgs, const LinPtrs);
         typedef void (*LinPersistGen)(const LinArgs, const BatchArgs);
         const LinPersist fn = which == 0 ? lin_persist_kernel<3, 12, 20, 9, false> : lin_persist_kernel<3, 0, 0, 0, false>;
-        const LinPersistGen fng = which == 0 ? lin_persist_kernel<3, 12, 20, 9, true> : lin_persist_kernel<3, 0, 0, 0, true>;
+        // (the drawing form keeps the run-time k-step loop: two inlined copies of a draw round instead of nine)
+        const LinPersistGen fng = which == 0 ? lin_persist_kernel<3, 12, 20, 0, true> : lin_persist_kernel<3, 0, 0, 0, true>;
         if (int rc = set_attr(gen ? (const void*)fng : (const void*)fn)) return rc;
         if (int rc = lin_ensure_init(c, w, ws, st)) return rc;
         for (int s0 = 0; s0 < n_steps; s0 += kLinMaxPersist) {
@@ -1586,6 +1589,46 @@ int lin_train_steps_gen(vaek_ctx* c, float* params, float* grads, float* m, floa
                         float lr, void* ws, hipStream_t st) {
     return lin_train_steps_impl(c, params, grads, m, v, step_dev, nullptr, nullptr, nullptr, &gen, n_steps, lr, ws, st);
 }
+
+// ---- the two halves of ONE step of the launch-per-step form, for a host-side collective between them ------------------------------
+// Data parallel without the P2P communicator (GradExchange mode "rccl"): the moment matrix is additive over the ranks' shards
+// (the loss is a batch mean, networks.py:97-98), so a rank forms the M of its shard (lin_moments: streamers, then reducers, two
+// launches ordered by the stream), torch.distributed sums the 12 KB float64 image over the ranks (RCCL; gloo in rehearsal -- every
+// rank receives the same bits), and every rank applies the identical update (lin_update: rows = the GLOBAL batch).
+size_t lin_moment_len(const vaek_ctx* c) { return lin_steps_shape_ok(c) ? (size_t)lin_no(c) : 0; }
+int lin_moments(vaek_ctx* c, const float* x, const float* z1, const float* z2, double* M_out, void* ws, hipStream_t st) {
+    const int NB = lin_nb(c), no = lin_no(c), ntiles = lin_ntiles(c);
+    const LinWs w = lin_carve(c, static_cast<char*>(ws) + c->ws_lin);
+    const int which = (c->D == 12 && c->L == 20) ? 0 : (NB <= 3 ? 1 : 2);
+    typedef void (*LinKernel)(const LinArgs);
+    const LinKernel fn = which == 0 ? lin_step_kernel<3, 12, 20> : which == 1 ? lin_step_kernel<3, 0, 0> : lin_step_kernel<4, 0, 0>;
+    VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinMaxLds));
+    const size_t lds = lin_lds_need(c);
+    LinArgs a{};
+    lin_fill_common(c, a, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
+    a.n_stream = ntiles; a.x = x; a.z1 = z1; a.z2 = z2; a.partial_out = w.partial;
+    { ProfScope ps("lin_moments_stream", st); launch_k(ps, fn, dim3((unsigned)ntiles), dim3(LNT), lds, st, a); }
+    a.n_stream = 0; a.n_reduce = no / 32; a.partial_in = w.partial; a.M_out = M_out;
+    a.comm = LinComm{}; a.comm.world = 1;                      // the ranks meet on the host, not in the reducers
+    { ProfScope ps("lin_moments_reduce", st); launch_k(ps, fn, dim3((unsigned)a.n_reduce), dim3(LNT), lds, st, a); }
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+int lin_update(vaek_ctx* c, float* params, float* grads, float* m, float* v, int32_t* step_dev, const double* M_in, float lr, hipStream_t st) {
+    const int NB = lin_nb(c);
+    const int which = (c->D == 12 && c->L == 20) ? 0 : (NB <= 3 ? 1 : 2);
+    typedef void (*LinKernel)(const LinArgs);
+    const LinKernel fn = which == 0 ? lin_step_kernel<3, 12, 20> : which == 1 ? lin_step_kernel<3, 0, 0> : lin_step_kernel<4, 0, 0>;
+    VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLinMaxLds));
+    LinArgs a{};
+    lin_fill_common(c, a, params, grads, m, v, step_dev, lr);
+    a.has_update = 1; a.M_in = M_in;
+    ProfScope ps("lin_moments_update", st);
+    launch_k(ps, fn, dim3(1), dim3(LNT), lin_lds_need(c), st, a);
+    VAEK_HIP_CHECK(hipGetLastError());
+    return VAEK_OK;
+}
+bool lin_moments_supported(const vaek_ctx* c) { return lin_steps_shape_ok(c); }
 
 // synchronous: did a bounded wait of the persistent form ever give up (a workgroup that never became resident, a lost store)?
 // The word is STICKY -- no launch clears it, and while it is set every wait of every later launch returns at once (the grid

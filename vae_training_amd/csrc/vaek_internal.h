@@ -295,6 +295,10 @@ int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v
                     const float* const* z1s, const float* const* z2s, int n_steps, float lr, void* ws, hipStream_t st);
 int lin_steps_status(vaek_ctx* c, void* ws, int* gave_up);
 bool lin_steps_gen_supported(const vaek_ctx* c, int kind);
+bool lin_moments_supported(const vaek_ctx* c);
+size_t lin_moment_len(const vaek_ctx* c);
+int lin_moments(vaek_ctx* c, const float* x, const float* z1, const float* z2, double* M_out, void* ws, hipStream_t st);
+int lin_update(vaek_ctx* c, float* params, float* grads, float* m, float* v, int32_t* step_dev, const double* M_in, float lr, hipStream_t st);
 struct BatchArgs;
 int lin_train_steps_gen(vaek_ctx* c, float* params, float* grads, float* m, float* v, int32_t* step_dev, const BatchArgs& gen, int n_steps,
                         float lr, void* ws, hipStream_t st);

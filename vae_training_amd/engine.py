@@ -167,6 +167,22 @@ class Engine:
             check(fn(*args, _stream()))
         return run
 
+    def moment_len(self):
+        """doubles in the second-moment image of a batch (0: the moment form does not cover this model)."""
+        n = C.c_int64()
+        _lib.check(self.lib.vaek_train_steps_moment_len(self.h, C.byref(n)))
+        return int(n.value)
+
+    def moments(self, x, z1, z2, M):
+        """M (float64 device tensor of moment_len()) <- the second-moment image of this rank's batch shard (vaek_train_steps_moments)."""
+        assert M.dtype == torch.float64 and M.numel() >= self.moment_len()
+        _lib.check(self.lib.vaek_train_steps_moments(self.h, _ptr(x), _ptr(z1), _ptr(z2), _ptr(M), _ptr(self.workspace), _stream()))
+
+    def moments_update(self, params, grads, m, v, step_dev, M, lr):
+        """loss, gradients, Adam from the (globally summed) moment image (vaek_train_steps_update)."""
+        _lib.check(self.lib.vaek_train_steps_update(self.h, _ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(step_dev), _ptr(M), float(lr),
+                                                    _ptr(self.workspace), _stream()))
+
     def train_steps_gave_up(self):
         """Synchronous: True if a bounded wait inside vaek_train_steps' persistent launch ever expired."""
         f = C.c_int32()

@@ -168,6 +168,10 @@ class VAE:
         lr = optimizer.optimizer_def.learning_rate
         if optimizer.exchange is None or optimizer.exchange.in_library:
             eng.train_step(model.flat, st.grads, st.m, st.v, st.step_dev, x, z1, z2, lr)
+        elif eng.moment_len() > 0:
+            # linear VAE over RCCL: the batch's second-moment matrix (additive over the shards) is what the collective sums --
+            # vaek_train_steps' arithmetic without the P2P communicator
+            optimizer.exchange.moments_step(model.flat, st.grads, st.m, st.v, st.step_dev, x, z1, z2, lr)
         elif eng.fused:
             eng.grads_only(model.flat, st.grads, st.step_dev, x, z1, z2)
             optimizer.exchange.all_reduce(st.grads)

@@ -135,6 +135,20 @@ class GradExchange:
         main.wait_stream(self._comm_stream)
         return grads
 
+    # ---- linear VAEs without the P2P communicator: the batch's second-moment matrix summed by the collective --------------------
+    def moments_step(self, params, grads, m, v, step_dev, x, z1, z2, lr):
+        """One data-parallel train step of a linear VAE through its sufficient statistic (csrc/linear_moments.hip): every rank
+        forms the moment image of its shard, ONE all-reduce sums the 12 KB float64 image (instead of the flat gradient: the
+        statistic is what the batch mean of networks.py:97-98 makes additive), and the same update runs everywhere --
+        vaek_train_steps' arithmetic with a host collective where the persistent launch exchanges granules.  Replicas stay
+        bitwise identical (every rank receives the same sum)."""
+        eng = self.engine
+        if not hasattr(self, "_M"):
+            self._M = torch.zeros(eng.moment_len(), dtype=torch.float64, device=eng.device)
+        eng.moments(x, z1, z2, self._M)
+        self.all_reduce(self._M)
+        eng.moments_update(params, grads, m, v, step_dev, self._M, lr)
+
     def all_reduce(self, grads: torch.Tensor):
         """SUM over ranks, in place (RCCL; gloo for CPU tensors and one-GPU rehearsals)."""
         if self.world == 1:
