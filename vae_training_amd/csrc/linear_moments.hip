@@ -1273,17 +1273,19 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
         auto issue_piece = [&](int k) __attribute__((always_inline)) {   // k-th piece of this wave's share of that item
             if constexpr (!GEN) { if (nxt.on && k < npw) nxt.issue(tl, wave + LNW * k, lane); }
         };
-        // GEN: round k of item i's draw -- work item t + 512 k of the tile: (row, 0) = the row of x, (row, 1 + q) = block q of the row's
-        // latent stream (4 normals: columns 4 q .. of [z1 | z2]); rows past the batch end are written as zeros
-        [[maybe_unused]] const int gD = DT ? DT : a.D, gL = LT ? LT : a.L, per_row = 1 + (gL + gD + 3) / 4;
-        [[maybe_unused]] const int gen_items = a.T * per_row, gen_rounds = (gen_items + LNT - 1) / LNT;
+        // GEN: round k of item i's draw -- work item w = t + 512 k of the tile: the first T items are the rows of x, item T + row * nzb + q
+        // is block q of the row's latent stream (4 normals: columns 4 q .. of [z1 | z2]) -- so all but one wave of a round run ONE of
+        // the two kinds of work; rows past the batch end are written as zeros
+        [[maybe_unused]] const int gD = DT ? DT : a.D, gL = LT ? LT : a.L, nzb = (gL + gD + 3) / 4;
+        [[maybe_unused]] const int gen_items = a.T * (1 + nzb), gen_rounds = (gen_items + LNT - 1) / LNT;
         [[maybe_unused]] const unsigned step0 = (unsigned)a.step_dev[0];          // (the updater stores the counter at the very end of the launch)
         auto gen_round = [&](int i, int k) __attribute__((always_inline)) {
             if constexpr (GEN) {
                 const int w = t + LNT * k;
                 if (i < items && k < gen_rounds && w < gen_items) {
                     const uint2 key = make_uint2((unsigned)src.seed, (unsigned)(src.seed >> 32));
-                    const int r = w / per_row, q = w - r * per_row;
+                    const int zi = w - a.T;
+                    const int r = w < a.T ? w : zi / nzb, q = w < a.T ? 0 : 1 + (zi - r * nzb);
                     const long long lrow = (long long)item_tile(i) * a.T + r;
                     const bool live = lrow < a.B;
                     const long long grow = src.row0 + lrow;

@@ -18,13 +18,18 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
 }
 
 // Box-Muller on one Philox block: 4 words -> 4 normals.  u1 in (0,1) from 24 bits, u2 in [0,1) from 32.
+// On the hardware transcendentals: r = sqrt(-2 ln u1) = v_sqrt(-2 ln 2 * v_log(u1)) (v_log_f32 is log2), and v_sin_f32 / v_cos_f32 take
+// their argument in REVOLUTIONS, so cos(2 pi u2) is one instruction on u2 -- 6 quarter-rate instructions per block where the
+// library's logf / sincospif spent ~200 (the draw inside vaek_train_steps_gen's streamers runs at two waves per SIMD: nothing hides
+// a long dependent chain there).  Within 5e-6 of the float64 Box-Muller of oracle/philox.py (tests/test_rng.py); every generator
+// entry point shares this function, so they stay bit-identical to each other.
 __device__ __forceinline__ void normals4(uint4 b, float (&n)[4]) {
     const float u1a = ((float)(b.x >> 8) + 0.5f) * 5.9604644775390625e-08f, u1b = ((float)(b.z >> 8) + 0.5f) * 5.9604644775390625e-08f;
-    const float ra = sqrtf(-2.f * logf(u1a)), rb = sqrtf(-2.f * logf(u1b));
-    float sa, ca, sb, cb;
-    sincospif(2.f * ((float)b.y * 2.3283064365386963e-10f), &sa, &ca);
-    sincospif(2.f * ((float)b.w * 2.3283064365386963e-10f), &sb, &cb);
-    n[0] = ra * ca; n[1] = ra * sa; n[2] = rb * cb; n[3] = rb * sb;
+    const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1a));
+    const float rb = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1b));
+    const float ta = (float)b.y * 2.3283064365386963e-10f, tb = (float)b.w * 2.3283064365386963e-10f;
+    n[0] = ra * __builtin_amdgcn_cosf(ta); n[1] = ra * __builtin_amdgcn_sinf(ta);
+    n[2] = rb * __builtin_amdgcn_cosf(tb); n[3] = rb * __builtin_amdgcn_sinf(tb);
 }
 
 struct NormalStream {           // sequential normals of one row
