@@ -1273,51 +1273,63 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
         auto issue_piece = [&](int k) __attribute__((always_inline)) {   // k-th piece of this wave's share of that item
             if constexpr (!GEN) { if (nxt.on && k < npw) nxt.issue(tl, wave + LNW * k, lane); }
         };
-        // GEN: round k of item i's draw -- work item w = t + 512 k of the tile: the first T items are the rows of x, item T + row * nzb + q
-        // is block q of the row's latent stream (4 normals: columns 4 q .. of [z1 | z2]) -- so all but one wave of a round run ONE of
-        // the two kinds of work; rows past the batch end are written as zeros
+        // GEN: the draw of item i in ROUNDS dealt to the 512 threads: round 0 = the rows of x (thread = row), round 1 + kk = the
+        // latent blocks 1024 kk + t and 1024 kk + 512 + t of the tile (block z = row * nzb + q: 4 normals, columns 4 q .. of [z1 | z2]) --
+        // two INDEPENDENT Philox chains per thread and round: at two waves per SIMD a single dependent chain of ten multiply
+        // rounds leaves the vector pipe idle most of the time.  Rows past the batch end are written as zeros.
         [[maybe_unused]] const int gD = DT ? DT : a.D, gL = LT ? LT : a.L, nzb = (gL + gD + 3) / 4;
-        [[maybe_unused]] const int gen_items = a.T * (1 + nzb), gen_rounds = (gen_items + LNT - 1) / LNT;
+        [[maybe_unused]] const int nlat = a.T * nzb, gen_rounds = 1 + (nlat + 2 * LNT - 1) / (2 * LNT);
         [[maybe_unused]] const unsigned step0 = (unsigned)a.step_dev[0];          // (the updater stores the counter at the very end of the launch)
         auto gen_round = [&](int i, int k) __attribute__((always_inline)) {
             if constexpr (GEN) {
-                const int w = t + LNT * k;
-                if (i < items && k < gen_rounds && w < gen_items) {
+                if (i < items && k < gen_rounds) {
                     const uint2 key = make_uint2((unsigned)src.seed, (unsigned)(src.seed >> 32));
-                    const int zi = w - a.T;
-                    const int r = w < a.T ? w : zi / nzb, q = w < a.T ? 0 : 1 + (zi - r * nzb);
-                    const long long lrow = (long long)item_tile(i) * a.T + r;
-                    const bool live = lrow < a.B;
-                    const long long grow = src.row0 + lrow;
+                    const long long row_lo = (long long)item_tile(i) * a.T;
                     const unsigned step = step0 + (unsigned)item_batch(i);
                     char* slot = lin_smem + (i % 3) * stride;
-                    if (q == 0) {
-                        float nrm[16];
-                        if (live) dataset_normals(src, step, grow, key, nrm);
-                        float* xr = reinterpret_cast<float*>(slot + tl.oX) + r * gD;
-                        for (int c0 = 0; c0 < gD; c0 += 4) {
-                            float o[4] = {0.f, 0.f, 0.f, 0.f};
-                            if (live) dataset_cols4(src, step, grow, key, nrm, c0, o);
-                            if (gD % 4 == 0) *reinterpret_cast<f32x4*>(xr + c0) = f32x4{o[0], o[1], o[2], o[3]};
-                            else {
+                    if (k == 0) {
+                        if (t < a.T) {
+                            const long long lrow = row_lo + t, grow = src.row0 + lrow;
+                            const bool live = lrow < a.B;
+                            float nrm[16];
+                            if (live) dataset_normals(src, step, grow, key, nrm);
+                            float* xr = reinterpret_cast<float*>(slot + tl.oX) + t * gD;
+                            for (int c0 = 0; c0 < gD; c0 += 4) {
+                                float o[4] = {0.f, 0.f, 0.f, 0.f};
+                                if (live) dataset_cols4(src, step, grow, key, nrm, c0, o);
+                                if (gD % 4 == 0) *reinterpret_cast<f32x4*>(xr + c0) = f32x4{o[0], o[1], o[2], o[3]};
+                                else {
 #pragma unroll
-                                for (int c = 0; c < 4; ++c) if (c0 + c < gD) xr[c0 + c] = o[c];
+                                    for (int c = 0; c < 4; ++c) if (c0 + c < gD) xr[c0 + c] = o[c];
+                                }
                             }
                         }
                     } else {
-                        float n4[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (live) latent_block(src, step, grow, key, q - 1, n4);
-                        const int c0 = 4 * (q - 1);
-                        float* z1r = reinterpret_cast<float*>(slot) + r * gL;
-                        float* z2r = reinterpret_cast<float*>(slot + tl.oZ2) + r * gD;
-                        if (c0 + 3 < gL && gL % 4 == 0) *reinterpret_cast<f32x4*>(z1r + c0) = f32x4{n4[0], n4[1], n4[2], n4[3]};
-                        else if (c0 >= gL && (c0 - gL) + 3 < gD && gD % 4 == 0 && gL % 4 == 0) *reinterpret_cast<f32x4*>(z2r + (c0 - gL)) = f32x4{n4[0], n4[1], n4[2], n4[3]};
-                        else {
+                        const int za = 2 * LNT * (k - 1) + t, zb = za + LNT;
+                        if (za < nlat) {
+                            const int zbc = min(zb, nlat - 1);
+                            const int ra = za / nzb, qa = za - ra * nzb, rb = zbc / nzb, qb = zbc - rb * nzb;
+                            const bool la = row_lo + ra < a.B, lb = row_lo + rb < a.B;
+                            float na[4], nb[4];
+                            latent_block(src, step, src.row0 + row_lo + ra, key, qa, na);
+                            latent_block(src, step, src.row0 + row_lo + rb, key, qb, nb);
+                            auto put = [&](int r, int q, bool live, const float (&n4)[4]) __attribute__((always_inline)) {
+                                const f32x4 v4 = live ? f32x4{n4[0], n4[1], n4[2], n4[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+                                const int c0 = 4 * q;
+                                float* z1r = reinterpret_cast<float*>(slot) + r * gL;
+                                float* z2r = reinterpret_cast<float*>(slot + tl.oZ2) + r * gD;
+                                if (c0 + 3 < gL && gL % 4 == 0) *reinterpret_cast<f32x4*>(z1r + c0) = v4;
+                                else if (c0 >= gL && (c0 - gL) + 3 < gD && gD % 4 == 0 && gL % 4 == 0) *reinterpret_cast<f32x4*>(z2r + (c0 - gL)) = v4;
+                                else {
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                if (c0 + c < gL) z1r[c0 + c] = n4[c];
-                                else if (c0 + c < gL + gD) z2r[c0 + c - gL] = n4[c];
-                            }
+                                    for (int c = 0; c < 4; ++c) {
+                                        if (c0 + c < gL) z1r[c0 + c] = v4[c];
+                                        else if (c0 + c < gL + gD) z2r[c0 + c - gL] = v4[c];
+                                    }
+                                }
+                            };
+                            put(ra, qa, la, na);
+                            if (zb < nlat) put(rb, qb, lb, nb);
                         }
                     }
                 }
