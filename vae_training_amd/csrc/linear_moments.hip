@@ -1249,6 +1249,10 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
                 tab[t] = n < N ? (which == 0 ? src.x : which == 1 ? src.z1 : src.z2)[n] : nullptr;
             }
         }
+        [[maybe_unused]] float* const Amat = reinterpret_cast<float*>(lin_smem + c_off + 16);     // GEN: the dataset's mixing matrix (<= 16 x 16), where the other form keeps its pointer tables
+        if constexpr (GEN) {
+            if (src.kind == 0 && t < src.dd * src.did) Amat[t] = src.A[t];
+        }
         const int valid_last = a.B - (a.ntiles - 1) * a.T;              // rows of a batch's last tile
         lin_write_vcol(reinterpret_cast<float*>(lin_smem + v_off), a.T, a.T, t);
         lin_write_vcol(reinterpret_cast<float*>(lin_smem + vr_off), a.T, valid_last, t);
@@ -1273,13 +1277,19 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
         auto issue_piece = [&](int k) __attribute__((always_inline)) {   // k-th piece of this wave's share of that item
             if constexpr (!GEN) { if (nxt.on && k < npw) nxt.issue(tl, wave + LNW * k, lane); }
         };
-        // GEN: the draw of item i in ROUNDS dealt to the 512 threads: round 0 = the rows of x (thread = row), round 1 + kk = the
-        // latent blocks 1024 kk + t and 1024 kk + 512 + t of the tile (block z = row * nzb + q: 4 normals, columns 4 q .. of [z1 | z2]) --
-        // two INDEPENDENT Philox chains per thread and round: at two waves per SIMD a single dependent chain of ten multiply
-        // rounds leaves the vector pipe idle most of the time.  Rows past the batch end are written as zeros.
+        // GEN: the draw of item i in ROUNDS dealt to the 512 threads.  A unit of work is a row of x or one latent block (4 normals:
+        // block z = row * nzb + q holds columns 4 q .. of the row's [z1 | z2]); rounds 1 .. npair give every thread TWO latent blocks
+        // (1024 (k - 1) + t and + 512), round 0 the rows of x to threads [0, T) and the first 512 left-over latent blocks to the
+        // threads from the top down, a last round what is still left: at the metric's shape 5 or 6 units per wave, one wave doing
+        // both kinds of work (rows first / blocks first with equal rounds for everybody left three waves idle for a round while four
+        // others worked: 2 us at the barrier behind the products).  Rows past the batch end are written as zeros.
         [[maybe_unused]] const int gD = DT ? DT : a.D, gL = LT ? LT : a.L, nzb = (gL + gD + 3) / 4;
-        [[maybe_unused]] const int nlat = a.T * nzb, gen_rounds = 1 + (nlat + 2 * LNT - 1) / (2 * LNT);
+        [[maybe_unused]] const int nlat = a.T * nzb, npair = nlat / (2 * LNT), rem = nlat - 2 * LNT * npair, rem0 = min(rem, LNT), rem1 = rem - rem0;
+        [[maybe_unused]] const int gen_rounds = 1 + npair + (rem1 > 0 ? 1 : 0);
         [[maybe_unused]] const unsigned step0 = (unsigned)a.step_dev[0];          // (the updater stores the counter at the very end of the launch)
+        // (copies: read through `src` the generator's scalars are re-fetched from the kernel-argument segment inside the loops)
+        [[maybe_unused]] int g_kind = 0, g_dd = 0, g_did = 0; [[maybe_unused]] float g_noise = 0.f; [[maybe_unused]] unsigned g_tag = 0;
+        if constexpr (GEN) { g_kind = src.kind; g_dd = src.dd; g_did = src.did; g_noise = src.noise_std; g_tag = src.tag; }
         auto gen_round = [&](int i, int k) __attribute__((always_inline)) {
             if constexpr (GEN) {
                 if (i < items && k < gen_rounds) {
@@ -1287,49 +1297,88 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
                     const long long row_lo = (long long)item_tile(i) * a.T;
                     const unsigned step = step0 + (unsigned)item_batch(i);
                     char* slot = lin_smem + (i % 3) * stride;
-                    if (k == 0) {
-                        if (t < a.T) {
+                    auto put = [&](int z, const float (&n4)[4]) __attribute__((always_inline)) {      // latent block z of the tile
+                        const int r = z / nzb, q = z - r * nzb, c0 = 4 * q;
+                        const bool live = row_lo + r < a.B;
+                        const f32x4 v4 = live ? f32x4{n4[0], n4[1], n4[2], n4[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+                        float* z1r = reinterpret_cast<float*>(slot) + r * gL;
+                        float* z2r = reinterpret_cast<float*>(slot + tl.oZ2) + r * gD;
+                        if (c0 + 3 < gL && gL % 4 == 0) *reinterpret_cast<f32x4*>(z1r + c0) = v4;
+                        else if (c0 >= gL && (c0 - gL) + 3 < gD && gD % 4 == 0 && gL % 4 == 0) *reinterpret_cast<f32x4*>(z2r + (c0 - gL)) = v4;
+                        else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                if (c0 + c < gL) z1r[c0 + c] = v4[c];
+                                else if (c0 + c < gL + gD) z2r[c0 + c - gL] = v4[c];
+                            }
+                        }
+                    };
+                    auto draw = [&](int z, float (&n4)[4]) __attribute__((always_inline)) {
+                        const int r = z / nzb;
+                        latent_block(src, step, src.row0 + row_lo + r, key, z - r * nzb, n4);
+                    };
+                    if (k >= 1 && k <= npair) {
+                        const int za = 2 * LNT * (k - 1) + t;
+                        float na[4], nb[4];
+                        draw(za, na); draw(za + LNT, nb);
+                        put(za, na); put(za + LNT, nb);
+                    } else {
+                        if (k == 0 && t < a.T) {
+                            // the row of x (datasets.py:183-195 / :75-84), the arithmetic of rng_dev.h's dataset_cols4 step for step --
+                            // with the mixing matrix read from LDS (through the scalar cache its loads cost 2.8 us per tile)
                             const long long lrow = row_lo + t, grow = src.row0 + lrow;
                             const bool live = lrow < a.B;
                             float nrm[16];
-                            if (live) dataset_normals(src, step, grow, key, nrm);
+                            dataset_normals(src, step, grow, key, nrm);
                             float* xr = reinterpret_cast<float*>(slot + tl.oX) + t * gD;
+                            float inv = 0.f;
+                            if (g_kind == 2) {
+                                float nsq = 0.f;
+#pragma unroll
+                                for (int d = 0; d < 16; ++d) if (d < g_dd) nsq = fmaf(nrm[d], nrm[d], nsq);
+                                inv = 1.f / sqrtf(nsq);
+                            }
                             for (int c0 = 0; c0 < gD; c0 += 4) {
                                 float o[4] = {0.f, 0.f, 0.f, 0.f};
-                                if (live) dataset_cols4(src, step, grow, key, nrm, c0, o);
-                                if (gD % 4 == 0) *reinterpret_cast<f32x4*>(xr + c0) = f32x4{o[0], o[1], o[2], o[3]};
+                                if (c0 < g_dd) {
+#pragma unroll
+                                    for (int c = 0; c < 4; ++c) {
+                                        const int d = c0 + c;
+                                        float v = 0.f;
+                                        if (d < g_dd) {
+                                            if (g_kind == 0) {
+#pragma unroll
+                                                for (int kk = 0; kk < 16; ++kk) if (kk < g_did) v = fmaf(Amat[d * g_did + kk], nrm[kk], v);
+                                            } else {
+#pragma unroll
+                                                for (int kk = 0; kk < 16; ++kk) v = (kk == d) ? nrm[kk] : v;
+                                                v *= inv;
+                                            }
+                                        }
+                                        o[c] = v;
+                                    }
+                                }
+                                if (g_kind == 0 && g_noise > 0.f) {      // noise normals: blocks (did+3)/4 .. of the same stream
+                                    float n4[4];
+                                    normals4(philox4x32_10(make_uint4((unsigned)grow, (unsigned)((g_did + 3) / 4 + c0 / 4), step, g_tag), key), n4);
+#pragma unroll
+                                    for (int c = 0; c < 4; ++c) o[c] = fmaf(g_noise, n4[c], o[c]);
+                                }
+                                const f32x4 v4 = live ? f32x4{o[0], o[1], o[2], o[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+                                if (gD % 4 == 0) *reinterpret_cast<f32x4*>(xr + c0) = v4;
                                 else {
 #pragma unroll
-                                    for (int c = 0; c < 4; ++c) if (c0 + c < gD) xr[c0 + c] = o[c];
+                                    for (int c = 0; c < 4; ++c) if (c0 + c < gD) xr[c0 + c] = v4[c];
                                 }
                             }
                         }
-                    } else {
-                        const int za = 2 * LNT * (k - 1) + t, zb = za + LNT;
-                        if (za < nlat) {
-                            const int zbc = min(zb, nlat - 1);
-                            const int ra = za / nzb, qa = za - ra * nzb, rb = zbc / nzb, qb = zbc - rb * nzb;
-                            const bool la = row_lo + ra < a.B, lb = row_lo + rb < a.B;
-                            float na[4], nb[4];
-                            latent_block(src, step, src.row0 + row_lo + ra, key, qa, na);
-                            latent_block(src, step, src.row0 + row_lo + rb, key, qb, nb);
-                            auto put = [&](int r, int q, bool live, const float (&n4)[4]) __attribute__((always_inline)) {
-                                const f32x4 v4 = live ? f32x4{n4[0], n4[1], n4[2], n4[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
-                                const int c0 = 4 * q;
-                                float* z1r = reinterpret_cast<float*>(slot) + r * gL;
-                                float* z2r = reinterpret_cast<float*>(slot + tl.oZ2) + r * gD;
-                                if (c0 + 3 < gL && gL % 4 == 0) *reinterpret_cast<f32x4*>(z1r + c0) = v4;
-                                else if (c0 >= gL && (c0 - gL) + 3 < gD && gD % 4 == 0 && gL % 4 == 0) *reinterpret_cast<f32x4*>(z2r + (c0 - gL)) = v4;
-                                else {
-#pragma unroll
-                                    for (int c = 0; c < 4; ++c) {
-                                        if (c0 + c < gL) z1r[c0 + c] = v4[c];
-                                        else if (c0 + c < gL + gD) z2r[c0 + c - gL] = v4[c];
-                                    }
-                                }
-                            };
-                            put(ra, qa, la, na);
-                            if (zb < nlat) put(rb, qb, lb, nb);
+                        // left-over latent blocks: round 0 from the top thread down, the last round from thread 0 up
+                        const int u = k == 0 ? LNT - 1 - t : t, cnt = k == 0 ? rem0 : rem1;
+                        if (u < cnt) {
+                            const int z = 2 * LNT * npair + (k == 0 ? 0 : rem0) + u;
+                            float n4[4];
+                            draw(z, n4);
+                            put(z, n4);
                         }
                     }
                 }
@@ -1363,13 +1412,33 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
             }
             LIN_NOWQ(s3);
             f32x4 acc[NB * (NB + 1) / 2];
-            prepare(i + 2);
-            lin_tile_products<NB, JT>(a, tl, lin_smem, (i % 3) * stride, ragged ? vr_off : v_off, c_off, acc, lane, wave,
-                                      [&](int j) __attribute__((always_inline)) { issue_piece(j); gen_round(i + 2, j); });
-            for (int k = (JT ? JT : a.T >> 5); k < npw; ++k) issue_piece(k);                   // (more pieces than k-steps: not at the shapes in use)
             if constexpr (GEN) {
+                // The draw of tile i + 2 (vector pipe) and the products of tile i (matrix pipe) are independent: the two waves of a
+                // SIMD take them in OPPOSITE order, so that one's Philox rounds run beside the other's MFMAs.  (Draw rounds placed
+                // between the k-steps, as the LDS-DMA pieces of the other form are, cost 4 us per tile: the long scalar state of both
+                // loops spilled, v_readlane by v_readlane, inside the hot loop.)
+                if (wave < LNW / 2) {
 #pragma unroll 1
-                for (int k = (JT ? JT : a.T >> 5); k < gen_rounds; ++k) gen_round(i + 2, k);
+                    for (int k = 0; k < gen_rounds; ++k) {
+                        [[maybe_unused]] unsigned long long g0 = 0, g1 = 0;
+                        LIN_NOWQ(g0);
+                        gen_round(i + 2, k);
+                        LIN_NOWQ(g1);
+#ifdef VAEK_LIN_STAMPS
+                        if (sid == 7 && t == 0 && g_lin_stamp_buf && k < 6) g_lin_stamp_buf[200 + k] += g1 - g0;
+#endif
+                    }
+                }
+                lin_tile_products<NB, JT>(a, tl, lin_smem, (i % 3) * stride, ragged ? vr_off : v_off, c_off, acc, lane, wave, [](int) {});
+                if (wave >= LNW / 2) {
+#pragma unroll 1
+                    for (int k = 0; k < gen_rounds; ++k) gen_round(i + 2, k);
+                }
+            } else {
+                prepare(i + 2);
+                lin_tile_products<NB, JT>(a, tl, lin_smem, (i % 3) * stride, ragged ? vr_off : v_off, c_off, acc, lane, wave,
+                                          [&](int j) __attribute__((always_inline)) { issue_piece(j); });
+                for (int k = (JT ? JT : a.T >> 5); k < npw; ++k) issue_piece(k);               // (more pieces than k-steps: not at the shapes in use)
             }
             LIN_NOWQ(s5);
             lin_barrier();                                     // every wave has read its last operand: the slot turns into scratch
@@ -1541,8 +1610,7 @@ static int lin_train_steps_impl(vaek_ctx* c, float* params, float* grads, float*
         typedef void (*LinPersist)(const LinArgs, const LinPtrs);
         typedef void (*LinPersistGen)(const LinArgs, const BatchArgs);
         const LinPersist fn = which == 0 ? lin_persist_kernel<3, 12, 20, 9, false> : lin_persist_kernel<3, 0, 0, 0, false>;
-        // (the drawing form keeps the run-time k-step loop: two inlined copies of a draw round instead of nine)
-        const LinPersistGen fng = which == 0 ? lin_persist_kernel<3, 12, 20, 0, true> : lin_persist_kernel<3, 0, 0, 0, true>;
+        const LinPersistGen fng = which == 0 ? lin_persist_kernel<3, 12, 20, 9, true> : lin_persist_kernel<3, 0, 0, 0, true>;
         if (int rc = set_attr(gen ? (const void*)fng : (const void*)fn)) return rc;
         if (int rc = lin_ensure_init(c, w, ws, st)) return rc;
         for (int s0 = 0; s0 < n_steps; s0 += kLinMaxPersist) {
