@@ -2,7 +2,7 @@
 set -e
 cd $GRAFT_REPO_ROOT/vae_training_amd/csrc
 mkdir -p /tmp/linst && for f in $(ls *.hip | sed "s/\.hip$//"); do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -DVAEK_LIN_STAMPS -c $f.hip -o /tmp/linst/$f.o &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -DVAEK_LIN_STAMPS=${STAMPS:-1} -c $f.hip -o /tmp/linst/$f.o &
 done; wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/linst/libvaek.so /tmp/linst/*.o
 cd $GRAFT_REPO_ROOT

@@ -89,13 +89,18 @@ struct LinArgs {
     float* params; float* grads; float* m; float* v; int32_t* step_dev; float lr;
     float inv_bt, eps_cli, rows, rows_over_bt; int off_eps, P;
     float* loss_hist; long long loss_hist_cap;
+    int stagger;                                  // streamers: waves 4 .. 7 enter a tile's products this many 64-cycle sleeps late (see there)
     LinComm comm;
 };
 
+#ifndef VAEK_LIN_ABL         // diagnostic builds (tools/lin_ablate.sh): 1 pieces issued in front of the products, 2 no MFMAs, 4 no image store,
+#define VAEK_LIN_ABL 0       //   8 no LDS-DMA at all (the slots keep whatever they hold).  Results are garbage unless 0.
+#endif
 #ifdef VAEK_LIN_STAMPS      // diagnostic build (tools/lin_stamps.sh): s_memtime at the updater's phase boundaries, into a buffer nothing reads
 __device__ unsigned long long* g_lin_stamp_buf = nullptr;
 #define LIN_STAMP(i)                                                                                         \
     do {                                                                                                     \
+        if (VAEK_LIN_STAMPS == 2) break;      /* light build: only the drain-free time stamps (LIN_NOWQ) */    \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         unsigned long long _t;                                                                               \
         unsigned long long _r;                                                                               \
@@ -106,7 +111,8 @@ __device__ unsigned long long* g_lin_stamp_buf = nullptr;
 #define LIN_NOW(v)                                                                                           \
     do {                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory"); \
+        if (VAEK_LIN_STAMPS == 2) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");             \
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory"); \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
     } while (0)
 #define LIN_NOWQ(v)  /* no vmcnt wait: does not drain the wave's stores */                                   \
@@ -132,13 +138,16 @@ template <int N> __device__ __forceinline__ void lin_wait_vmcnt() { asm volatile
 // Workgroup barrier that leaves LDS-DMA loads in flight: __syncthreads() would drain them (its fence waits vmcnt(0) while a
 // global_load_lds is pending: cdna guide, LDS-DMA rules); LDS traffic of this wave is waited for explicitly.
 __device__ __forceinline__ void lin_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// wait until at most n (wave-uniform, <= 12) of this wave's memory operations are outstanding
+// wait until at most n (wave-uniform, <= 20) of this wave's memory operations are outstanding
 __device__ __forceinline__ void lin_wait_vmcnt_upto(int n) {
     switch (n) {
         case 1: lin_wait_vmcnt<1>(); break;   case 2: lin_wait_vmcnt<2>(); break;   case 3: lin_wait_vmcnt<3>(); break;
         case 4: lin_wait_vmcnt<4>(); break;   case 5: lin_wait_vmcnt<5>(); break;   case 6: lin_wait_vmcnt<6>(); break;
         case 7: lin_wait_vmcnt<7>(); break;   case 8: lin_wait_vmcnt<8>(); break;   case 9: lin_wait_vmcnt<9>(); break;
         case 10: lin_wait_vmcnt<10>(); break; case 11: lin_wait_vmcnt<11>(); break; case 12: lin_wait_vmcnt<12>(); break;
+        case 13: lin_wait_vmcnt<13>(); break; case 14: lin_wait_vmcnt<14>(); break; case 15: lin_wait_vmcnt<15>(); break;
+        case 16: lin_wait_vmcnt<16>(); break; case 17: lin_wait_vmcnt<17>(); break; case 18: lin_wait_vmcnt<18>(); break;
+        case 19: lin_wait_vmcnt<19>(); break; case 20: lin_wait_vmcnt<20>(); break;
         default: lin_wait_vmcnt<0>(); break;
     }
 }
@@ -332,8 +341,9 @@ __device__ __forceinline__ void st_sc1_x4(float* p, f32x4 v) {
 // and the products of k-step j (the persistent streamers issue the LDS-DMA pieces of a later tile there: in the shadow of the
 // matrix pipe).  JT > 0: the k-step count at compile time -- the loop unrolls, the reads carry immediate offsets and the waits
 // are counted (with a run-time count hipcc waits lgkmcnt(0) before every group of products, prefetched operands included).
-constexpr int lin_scratch_bytes(int NB) { return LNW * (NB * (NB + 1) / 2) * 1024; }
-template <int NB, int JT, typename Hook>
+constexpr int lin_scratch_bytes(int NB) { return LNW * (NB * (NB + 1) / 2) * 1024; }       // (at 8 images; the persistent form's 4 need half)
+constexpr int kLinCW = 4;      // persistent form: waves 0 .. 3 multiply (one per SIMD), waves 4 .. 7 load
+template <int NB, int JT, int CW, typename Hook>
 __device__ __forceinline__ void lin_tile_products(const LinArgs& a, const LinTile& tl, const char* smem, int slot_off, int v_off, int c_off,
                                                   f32x4 (&acc)[NB * (NB + 1) / 2], int lane, int wave, Hook&& hook) {
     constexpr int NBLK = NB * (NB + 1) / 2;
@@ -351,17 +361,20 @@ __device__ __forceinline__ void lin_tile_products(const LinArgs& a, const LinTil
     }
 #pragma unroll
     for (int k = 0; k < NBLK; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // Wave w takes samples (T / 8) w .. + T / 8 - 1 in J = T / 32 k-steps of 4.  Within a run of 16 samples lane group g takes sample
+    // Wave w takes samples (T / CW) w .. + T / CW - 1 in J = T / (4 CW) k-steps of 4.  Within a run of 16 samples lane group g takes sample
     // s + 4 g in step s: four rows apart, i.e. 16 banks with 80- and 48-byte rows, so the lane groups one ds_read_b32 services
     // together never collide; a run shorter than 16 (T / 8 not a multiple of 16: its last r < 4 steps) takes s + r g.
-    const int J = JT ? JT : a.T >> 5, wbase = (a.T >> 3) * wave, jfull = J & ~3;
+    // (CW: the waves that share a tile's samples -- all 8 of the launch-per-step form, the 4 compute waves of the persistent one)
+    const int J = JT ? JT : a.T / (4 * CW), wbase = (a.T / CW) * wave, jfull = J & ~3;
     auto products = [&](const float (&op)[NB]) __attribute__((always_inline)) {
         int k = 0;
 #pragma unroll
         for (int b1 = 0; b1 < NB; ++b1)
 #pragma unroll
-            for (int b2 = b1; b2 < NB; ++b2, ++k)
-                acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(op[b1], op[b2], acc[k], 0, 0, 0);
+            for (int b2 = b1; b2 < NB; ++b2, ++k) {
+                if (VAEK_LIN_ABL & 2) acc[k][0] += op[b1] * op[b2];
+                else acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(op[b1], op[b2], acc[k], 0, 0, 0);
+            }
     };
     if constexpr (JT > 0) {
         // per-lane address of every feature's operand, advanced from k-step to k-step by adds only: + one sample inside a run of
@@ -423,17 +436,20 @@ __device__ __forceinline__ void lin_tile_products(const LinArgs& a, const LinTil
 // every wave has passed the barrier behind its products -- and leave as ONE image in the accumulators' own layout
 // [block][lane][4] (image element (row, col) of a block sits at ((row >> 2) * 16 + col) * 4 + (row & 3): lin_img_index), so the
 // sum reads and the store are 16 bytes per lane.
-template <int NB, bool SC1>
+template <int NB, bool SC1, int CW>
 __device__ __forceinline__ void lin_tile_combine(const f32x4 (&acc)[NB * (NB + 1) / 2], char* scratch, float* out, int t, int wave, int lane) {
     constexpr int NBLK = NB * (NB + 1) / 2;
     f32x4* scr = reinterpret_cast<f32x4*>(scratch);       // [wave][block][lane]
+    if (wave < CW) {
 #pragma unroll
-    for (int k = 0; k < NBLK; ++k) scr[(wave * NBLK + k) * 64 + lane] = acc[k];
+        for (int k = 0; k < NBLK; ++k) scr[(wave * NBLK + k) * 64 + lane] = acc[k];
+    }
     lin_barrier();
     for (int q = t; q < NBLK * 64; q += LNT) {
         f32x4 sum = scr[q];
 #pragma unroll
-        for (int w = 1; w < LNW; ++w) sum += scr[w * NBLK * 64 + q];
+        for (int w = 1; w < CW; ++w) sum += scr[w * NBLK * 64 + q];
+        if ((VAEK_LIN_ABL & 4) && sum[0] != 12345.f) continue;
         if (SC1) st_sc1_x4(out + 4 * q, sum); else *reinterpret_cast<f32x4*>(out + 4 * q) = sum;
     }
 }
@@ -908,7 +924,12 @@ struct LinUpdM {
                 // e^{lv / 2} and e^{eps / 2}, e^{-eps}: the same instruction stream for the latent lanes and the epsilon lane
                 const bool is_eps = i == off_eps;
                 const double e = is_eps ? pv * (double)a.eps_cli : pv, h = lin_exp(0.5 * e);
-                if (is_eps) { scal[0] = e; scal[1] = h; scal[2] = lin_exp(-e); }
+                if (is_eps) {
+                    const double q = h * h;
+                    double r = __builtin_amdgcn_rcp(q);                // 1 / sigma^2: hardware seed, two Newton steps (full double precision)
+                    r = fma(fma(-q, r, 1.0), r, r); r = fma(fma(-q, r, 1.0), r, r);
+                    scal[0] = e; scal[1] = h; scal[2] = r;
+                }
                 else { sd[i - off_epsp] = h; elv[i - off_epsp] = h * h; lvd[i - off_epsp] = pv; }
             }
         }
@@ -1145,9 +1166,9 @@ __global__ __launch_bounds__(LNT) void lin_step_kernel(const LinArgs a) {
         lin_barrier();
         lin_fix_ragged(a, tl, a.x, a.z1, a.z2, tile, lin_smem, t);
         f32x4 acc[NB * (NB + 1) / 2];
-        lin_tile_products<NB, 0>(a, tl, lin_smem, 0, v_off, c_off, acc, lane, wave, [](int) {});
+        lin_tile_products<NB, 0, LNW>(a, tl, lin_smem, 0, v_off, c_off, acc, lane, wave, [](int) {});
         lin_barrier();                                         // every wave has read its last operand: the slot turns into scratch
-        lin_tile_combine<NB, false>(acc, lin_smem, a.partial_out + (long long)tile * NO, t, wave, lane);
+        lin_tile_combine<NB, false, LNW>(acc, lin_smem, a.partial_out + (long long)tile * NO, t, wave, lane);
     }
 }
 
@@ -1193,7 +1214,7 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
             ++tstep;
             u.step(a, tstep, mreg, g, n + 1 < N ? a.cnt_reduce + n + 1 : nullptr, (unsigned)per_set, a.M_base + (long long)(n + 1) * NO, mnext, have_next);
             LIN_STAMP(7);
-            { [[maybe_unused]] unsigned long long te = 0; LIN_NOW(te); LIN_PUT(64 + n, te); }
+            { [[maybe_unused]] unsigned long long te = 0; LIN_NOWQ(te); LIN_PUT(64 + n, te); }
         }
         u.store_state(a, g, tstep);
         // every reducer has added to the last batch's counter, every streamer long before: nobody reads or writes the arrival
@@ -1259,7 +1280,14 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
         if (t == 0) *reinterpret_cast<float*>(lin_smem + c_off) = 0.f;
         __syncthreads();
         const int per_batch = sid < a.ntiles ? (a.ntiles - sid + S - 1) / S : 0, items = N * per_batch;
-        const int npw = GEN ? 0 : (wave < tl.np ? (tl.np - wave + LNW - 1) / LNW : 0);          // this wave's pieces of a tile
+        // Wave roles inside a streamer: waves 0 .. 3 (one per SIMD) multiply, waves 4 .. 7 load (LDS-DMA pieces of the tile two ahead,
+        // or its Philox draw): with all 8 waves doing both, each wave's ~650 scalar / vector / LDS instructions per tile and its 54
+        // MFMAs simply added up (streamers alone 4.7 us per tile; without the MFMAs 3.4, without the LDS-DMA 3.2, without both 2.1:
+        // tools/lin_ablate.sh) -- a wave cannot issue anything else while it waits for the matrix pipe to take its next MFMA.
+        const bool loader = wave >= kLinCW;
+        const int lw = wave - kLinCW;                                                            // loader waves: 0 .. NLW - 1
+        constexpr int NLW = LNW - kLinCW;
+        const int npw = (GEN || !loader) ? 0 : (lw < tl.np ? (tl.np - lw + NLW - 1) / NLW : 0);  // this wave's pieces of a tile
         const int sw = wave < (NO / 4 + 63) / 64 ? 1 : 0;                                        // does this wave store a share of an image?
         auto item_batch = [&](int i) { return i / per_batch; };
         auto item_tile = [&](int i) { return sid + (i % per_batch) * S; };
@@ -1275,22 +1303,22 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
             }
         };
         auto issue_piece = [&](int k) __attribute__((always_inline)) {   // k-th piece of this wave's share of that item
-            if constexpr (!GEN) { if (nxt.on && k < npw) nxt.issue(tl, wave + LNW * k, lane); }
+            if constexpr (!GEN) { if (!(VAEK_LIN_ABL & 8) && nxt.on && k < npw) nxt.issue(tl, lw + NLW * k, lane); }
         };
-        // GEN: the draw of item i in ROUNDS dealt to the 512 threads.  A unit of work is a row of x or one latent block (4 normals:
-        // block z = row * nzb + q holds columns 4 q .. of the row's [z1 | z2]); rounds 1 .. npair give every thread TWO latent blocks
-        // (1024 (k - 1) + t and + 512), round 0 the rows of x to threads [0, T) and the first 512 left-over latent blocks to the
-        // threads from the top down, a last round what is still left: at the metric's shape 5 or 6 units per wave, one wave doing
-        // both kinds of work (rows first / blocks first with equal rounds for everybody left three waves idle for a round while four
-        // others worked: 2 us at the barrier behind the products).  Rows past the batch end are written as zeros.
+        // GEN: the draw of item i in ROUNDS dealt to the GT = 256 threads of the loader waves.  A unit of work is a row of x or one
+        // latent block (4 normals: block z = row * nzb + q holds columns 4 q .. of the row's [z1 | z2]): first the rows of x (thread =
+        // row, ceil(T / GT) rounds), then rounds that give every thread TWO latent blocks (two independent Philox chains), then what
+        // is left, one block per thread.  Rows past the batch end are written as zeros.
+        constexpr int GT = NLW * 64;
+        [[maybe_unused]] const int gt = t - kLinCW * 64;
         [[maybe_unused]] const int gD = DT ? DT : a.D, gL = LT ? LT : a.L, nzb = (gL + gD + 3) / 4;
-        [[maybe_unused]] const int nlat = a.T * nzb, npair = nlat / (2 * LNT), rem = nlat - 2 * LNT * npair, rem0 = min(rem, LNT), rem1 = rem - rem0;
-        [[maybe_unused]] const int gen_rounds = 1 + npair + (rem1 > 0 ? 1 : 0);
+        [[maybe_unused]] const int nlat = a.T * nzb, xr = (a.T + GT - 1) / GT, npair = nlat / (2 * GT), rem = nlat - 2 * GT * npair;
+        [[maybe_unused]] const int gen_rounds = xr + npair + (rem + GT - 1) / GT;
         [[maybe_unused]] const unsigned step0 = (unsigned)a.step_dev[0];          // (the updater stores the counter at the very end of the launch)
         // (copies: read through `src` the generator's scalars are re-fetched from the kernel-argument segment inside the loops)
         [[maybe_unused]] int g_kind = 0, g_dd = 0, g_did = 0; [[maybe_unused]] float g_noise = 0.f; [[maybe_unused]] unsigned g_tag = 0;
         if constexpr (GEN) { g_kind = src.kind; g_dd = src.dd; g_did = src.did; g_noise = src.noise_std; g_tag = src.tag; }
-        auto gen_round = [&](int i, int k) __attribute__((always_inline)) {
+        auto gen_round = [&](int i, int k) __attribute__((always_inline)) {       // loader waves only
             if constexpr (GEN) {
                 if (i < items && k < gen_rounds) {
                     const uint2 key = make_uint2((unsigned)src.seed, (unsigned)(src.seed >> 32));
@@ -1317,20 +1345,28 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
                         const int r = z / nzb;
                         latent_block(src, step, src.row0 + row_lo + r, key, z - r * nzb, n4);
                     };
-                    if (k >= 1 && k <= npair) {
-                        const int za = 2 * LNT * (k - 1) + t;
+                    if (k >= xr && k < xr + npair) {
+                        const int za = 2 * GT * (k - xr) + gt;
                         float na[4], nb[4];
-                        draw(za, na); draw(za + LNT, nb);
-                        put(za, na); put(za + LNT, nb);
+                        draw(za, na); draw(za + GT, nb);
+                        put(za, na); put(za + GT, nb);
+                    } else if (k >= xr + npair) {
+                        const int z = 2 * GT * npair + GT * (k - xr - npair) + gt;
+                        if (z < nlat) {
+                            float n4[4];
+                            draw(z, n4);
+                            put(z, n4);
+                        }
                     } else {
-                        if (k == 0 && t < a.T) {
+                        const int row = gt + GT * k;
+                        if (row < a.T) {
                             // the row of x (datasets.py:183-195 / :75-84), the arithmetic of rng_dev.h's dataset_cols4 step for step --
                             // with the mixing matrix read from LDS (through the scalar cache its loads cost 2.8 us per tile)
-                            const long long lrow = row_lo + t, grow = src.row0 + lrow;
+                            const long long lrow = row_lo + row, grow = src.row0 + lrow;
                             const bool live = lrow < a.B;
                             float nrm[16];
                             dataset_normals(src, step, grow, key, nrm);
-                            float* xr = reinterpret_cast<float*>(slot + tl.oX) + t * gD;
+                            float* xr_ = reinterpret_cast<float*>(slot + tl.oX) + row * gD;
                             float inv = 0.f;
                             if (g_kind == 2) {
                                 float nsq = 0.f;
@@ -1365,20 +1401,12 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
                                     for (int c = 0; c < 4; ++c) o[c] = fmaf(g_noise, n4[c], o[c]);
                                 }
                                 const f32x4 v4 = live ? f32x4{o[0], o[1], o[2], o[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
-                                if (gD % 4 == 0) *reinterpret_cast<f32x4*>(xr + c0) = v4;
+                                if (gD % 4 == 0) *reinterpret_cast<f32x4*>(xr_ + c0) = v4;
                                 else {
 #pragma unroll
-                                    for (int c = 0; c < 4; ++c) if (c0 + c < gD) xr[c0 + c] = v4[c];
+                                    for (int c = 0; c < 4; ++c) if (c0 + c < gD) xr_[c0 + c] = v4[c];
                                 }
                             }
-                        }
-                        // left-over latent blocks: round 0 from the top thread down, the last round from thread 0 up
-                        const int u = k == 0 ? LNT - 1 - t : t, cnt = k == 0 ? rem0 : rem1;
-                        if (u < cnt) {
-                            const int z = 2 * LNT * npair + (k == 0 ? 0 : rem0) + u;
-                            float n4[4];
-                            draw(z, n4);
-                            put(z, n4);
                         }
                     }
                 }
@@ -1388,13 +1416,15 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
         auto signal = [&](int i) {                            // image of item i is out (ONE lane, behind every wave's drain + a barrier)
             if (t == 0) __hip_atomic_fetch_add(my_shard + item_batch(i) * kLinShards * kLinShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
-        prepare(0);
-        for (int k = 0; k < npw; ++k) issue_piece(k);
-        prepare(1);
-        for (int k = 0; k < npw; ++k) issue_piece(k);
-        if constexpr (GEN) {
+        if (loader) {
+            prepare(0);
+            for (int k = 0; k < npw; ++k) issue_piece(k);
+            prepare(1);
+            for (int k = 0; k < npw; ++k) issue_piece(k);
+            if constexpr (GEN) {
 #pragma unroll 1
-            for (int k = 0; k < 2 * gen_rounds; ++k) gen_round(k & 1, k >> 1);
+                for (int k = 0; k < 2 * gen_rounds; ++k) gen_round(k & 1, k >> 1);
+            }
         }
         [[maybe_unused]] unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, sacc_i = 0, sacc_l = 0, sacc_f = 0, sacc_m = 0, sacc_p = 0, sacc_b = 0;
         for (int i = 0; i < items; ++i) {
@@ -1412,43 +1442,40 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
             }
             LIN_NOWQ(s3);
             f32x4 acc[NB * (NB + 1) / 2];
-            if constexpr (GEN) {
-                // The draw of tile i + 2 (vector pipe) and the products of tile i (matrix pipe) are independent: the two waves of a
-                // SIMD take them in OPPOSITE order, so that one's Philox rounds run beside the other's MFMAs.  (Draw rounds placed
-                // between the k-steps, as the LDS-DMA pieces of the other form are, cost 4 us per tile: the long scalar state of both
-                // loops spilled, v_readlane by v_readlane, inside the hot loop.)
-                if (wave < LNW / 2) {
+            if (!loader) {
+                lin_tile_products<NB, JT, kLinCW>(a, tl, lin_smem, (i % 3) * stride, ragged ? vr_off : v_off, c_off, acc, lane, wave, [](int) {});
+            } else if constexpr (GEN) {
 #pragma unroll 1
-                    for (int k = 0; k < gen_rounds; ++k) {
-                        [[maybe_unused]] unsigned long long g0 = 0, g1 = 0;
-                        LIN_NOWQ(g0);
-                        gen_round(i + 2, k);
-                        LIN_NOWQ(g1);
+                for (int k = 0; k < gen_rounds; ++k) {
+                    [[maybe_unused]] unsigned long long g0 = 0, g1 = 0;
+                    LIN_NOWQ(g0);
+                    gen_round(i + 2, k);
+                    LIN_NOWQ(g1);
 #ifdef VAEK_LIN_STAMPS
-                        if (sid == 7 && t == 0 && g_lin_stamp_buf && k < 6) g_lin_stamp_buf[200 + k] += g1 - g0;
+                    if (sid == 7 && gt == 0 && g_lin_stamp_buf && k < 8) g_lin_stamp_buf[200 + k] += g1 - g0;
 #endif
-                    }
                 }
-                lin_tile_products<NB, JT>(a, tl, lin_smem, (i % 3) * stride, ragged ? vr_off : v_off, c_off, acc, lane, wave, [](int) {});
-                if (wave >= LNW / 2) {
-#pragma unroll 1
-                    for (int k = 0; k < gen_rounds; ++k) gen_round(i + 2, k);
-                }
-            } else {
+            } else if (i > 0) {
+                // (iteration 0 issues the pieces of tile 2 only behind its early signal: the drain in front of that signal would
+                // otherwise wait for them to land)
                 prepare(i + 2);
-                lin_tile_products<NB, JT>(a, tl, lin_smem, (i % 3) * stride, ragged ? vr_off : v_off, c_off, acc, lane, wave,
-                                          [&](int j) __attribute__((always_inline)) { issue_piece(j); });
-                for (int k = (JT ? JT : a.T >> 5); k < npw; ++k) issue_piece(k);               // (more pieces than k-steps: not at the shapes in use)
+                for (int k = 0; k < npw; ++k) issue_piece(k);
             }
             LIN_NOWQ(s5);
             lin_barrier();                                     // every wave has read its last operand: the slot turns into scratch
             LIN_NOWQ(s6);
-            lin_tile_combine<NB, true>(acc, slot, a.partial_base + ((long long)n * a.ntiles + tile) * NO, t, wave, lane);
+            lin_tile_combine<NB, true, kLinCW>(acc, slot, a.partial_base + ((long long)n * a.ntiles + tile) * NO, t, wave, lane);
             if (i == 0) {                                      // the launch's first image: out at once (pipeline fill), not two tiles later
                 lin_wait_vmcnt<0>();
                 lin_barrier();
                 signal(0);
                 if (sid == 0) { [[maybe_unused]] unsigned long long te = 0; LIN_NOWQ(te); LIN_PUT(53, te); }
+                if constexpr (!GEN) {
+                    if (loader) {
+                        prepare(2);
+                        for (int k = 0; k < npw; ++k) issue_piece(k);
+                    }
+                }
             }
             LIN_NOWQ(s4);
             if (i + 1 < items) { sacc_i += s1 - s0; sacc_l += s2 - s1; sacc_f += s3 - s2; sacc_m += s4 - s3; sacc_p += s5 - s3; sacc_b += s6 - s5; }
@@ -1500,7 +1527,7 @@ static int lin_tile_rows(const vaek_ctx* c) {
     if (smax < 16 || c->B <= 256 * smax) return 256;
     const int T = 32 * (int)(((long long)c->B + 32ll * smax - 1) / (32ll * smax));
     const LinTile tl(c->D, c->L, T);
-    return T <= 512 && (tl.np + LNW - 1) / LNW <= 12 && lin_ring_bytes(c, T) <= kLinMaxLds ? T : 256;
+    return T <= 512 && (tl.np + LNW - kLinCW - 1) / (LNW - kLinCW) <= 18 && lin_ring_bytes(c, T) <= kLinMaxLds ? T : 256;
 }
 static int lin_ntiles(const vaek_ctx* c) { const int T = lin_tile_rows(c); return (c->B + T - 1) / T; }
 static size_t lin_slot_stride(const vaek_ctx* c) {      // one tile slot, large enough to double as the combine's cross-wave scratch
@@ -1521,7 +1548,7 @@ static size_t lin_persist_lds(const vaek_ctx* c) {
 static bool lin_persist_supported(const vaek_ctx* c) {
     const LinTile tl(c->D, c->L, lin_tile_rows(c));
     return lin_steps_shape_ok(c) && lin_nb(c) == 3 && LinUpdM<3, 0, 0>::shape_ok(c->D, c->L) && lin_persist_lds(c) <= kLinMaxLds &&
-           (tl.np + LNW - 1) / LNW <= 12 && c->n_cu >= 1 + kLinReduceSets * kLinReduceWgs + 16;
+           (tl.np + LNW - kLinCW - 1) / (LNW - kLinCW) <= 18 && c->n_cu >= 1 + kLinReduceSets * kLinReduceWgs + 16;
 }
 // streamer workgroups of the persistent launch: the CUs the updater and the reducers leave, tiles dealt evenly
 static int lin_persist_streamers(const vaek_ctx* c) {
@@ -1567,6 +1594,8 @@ static int lin_fill_common(const vaek_ctx* c, LinArgs& a, float* params, float* 
             a.comm.peer[r] = reinterpret_cast<unsigned long long*>(static_cast<char*>(c->comm.peers[r]) + c->comm.lin_off);
     }
     a.loss_hist = c->loss_hist; a.loss_hist_cap = c->loss_hist_cap;
+    static const int stagger = getenv("VAEK_LIN_STAGGER") ? atoi(getenv("VAEK_LIN_STAGGER")) : 3;      // diagnostic override
+    a.stagger = stagger;
     return 0;
 }
 
@@ -1609,8 +1638,8 @@ static int lin_train_steps_impl(vaek_ctx* c, float* params, float* grads, float*
     if (persistent) {
         typedef void (*LinPersist)(const LinArgs, const LinPtrs);
         typedef void (*LinPersistGen)(const LinArgs, const BatchArgs);
-        const LinPersist fn = which == 0 ? lin_persist_kernel<3, 12, 20, 9, false> : lin_persist_kernel<3, 0, 0, 0, false>;
-        const LinPersistGen fng = which == 0 ? lin_persist_kernel<3, 12, 20, 9, true> : lin_persist_kernel<3, 0, 0, 0, true>;
+        const LinPersist fn = which == 0 ? lin_persist_kernel<3, 12, 20, 18, false> : lin_persist_kernel<3, 0, 0, 0, false>;
+        const LinPersistGen fng = which == 0 ? lin_persist_kernel<3, 12, 20, 18, true> : lin_persist_kernel<3, 0, 0, 0, true>;
         if (int rc = set_attr(gen ? (const void*)fng : (const void*)fn)) return rc;
         if (int rc = lin_ensure_init(c, w, ws, st)) return rc;
         for (int s0 = 0; s0 < n_steps; s0 += kLinMaxPersist) {
