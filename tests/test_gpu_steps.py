@@ -130,7 +130,9 @@ def test_pipelined_steps_refuse_what_they_cannot_do():
 
 def test_persistent_and_launch_per_step_forms_agree(monkeypatch):
     """The two schedules of vaek_train_steps (one persistent launch per 64 steps with in-launch hand-offs; n + 2 launches ordered
-    by the stream) run the same arithmetic in the same order: bitwise equal parameters, moments and losses.  A subprocess takes
+    by the stream) are the same train steps in two summation orders -- the persistent form sums a tile over 4 multiplying waves
+    and updates on the float64 matrix cores, the launch-per-step form sums over 8 waves and updates on the vector units: after 70
+    steps every loss within 2e-6 relative, parameters within 2e-6, Adam moments within 1e-5 of their scale.  A subprocess takes
     the launch-per-step form (the choice is read once per process)."""
     import os, subprocess, sys, json
     code = r"""
@@ -144,15 +146,18 @@ cfg, dk, _, lr = build("c1_linear_L20")
 p, batches = _problem(cfg, dk, 3000, 70)
 eng = engine_for(cfg, 3000)
 params, grads, m, v, step, losses = _run_pipelined(eng, cfg, p, batches, lr)
-print(json.dumps({"p": params.cpu().numpy().view(np.int32).tolist(), "m": m.cpu().numpy().view(np.int32).tolist(), "l": np.asarray(losses, np.float32).view(np.int32).tolist()}))
+print(json.dumps({"p": params.cpu().numpy().astype(np.float64).tolist(), "m": m.cpu().numpy().astype(np.float64).tolist(), "l": np.asarray(losses, np.float64).tolist()}))
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for persist in ("1", "0"):
         env = dict(os.environ, VAEK_LIN_PERSIST=persist)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
-    assert outs[0] == outs[1]
+        outs.append({k: np.asarray(v) for k, v in json.loads(r.stdout.strip().splitlines()[-1]).items()})
+    a, b = outs
+    assert np.max(np.abs(a["l"] - b["l"]) / np.abs(b["l"])) <= 2e-6
+    assert np.max(np.abs(a["p"] - b["p"])) <= 2e-6
+    assert np.max(np.abs(a["m"] - b["m"])) <= 1e-5 * np.max(np.abs(b["m"]))
 
 
 def test_graph_replay_of_pipelined_steps_equals_the_eager_call():
