@@ -343,6 +343,7 @@ def main():
                          "entry point whose launches overlap the pass over batch n + 2 with the Adam update of batch n")
     ap.add_argument("--graph", type=int, default=-1,
                     help="steps captured per hipGraph (0 = eager launches; -1 = auto: the largest even size <= 200 dividing --steps)")
+    ap.add_argument("--only-main", action="store_true", help="skip the A/B legs (per-sample path, fresh inputs): profiler passes")
     ap.add_argument("--repeat", type=int, default=20,
                     help="how many times the timed region of exactly --steps steps is run (each time behind its own Infinity Cache sweep, "
                          "barrier and synchronize); `value` is the MEDIAN region, min / max ride along")
@@ -424,10 +425,13 @@ def main():
     # communicator (same kernel at every N); without that communicator (RCCL transport) N > 1 takes the per-sample step.
     use_pipe = (exch is None or exch.in_library) and not args.no_pipeline and eng.supports_train_steps()
 
+    launched = [0]              # train steps issued on the main entry point so far (profiler tools divide counters by it)
+
     def run_group(i0, n):
         """n consecutive train steps on batches i0, i0 + 1, ... (mod the rotation)."""
         if n <= 0:
             return
+        launched[0] += n
         if use_pipe:
             eng.train_steps(params, grads, m, v, step_dev, [batches[(i0 + k) % len(batches)] for k in range(n)], lr)
         else:
@@ -477,13 +481,16 @@ def main():
                 run_group(0, gsteps)
         torch.cuda.current_stream().wait_stream(side)
         fence()                             # ranks leave capture at different times: line them up first
+        launched[0] -= gsteps               # (capture recorded, did not run, that group)
         graph.replay()                      # one untimed replay (graph upload)
+        launched[0] += gsteps
 
     plan = None
     if use_plan:
         gsteps = args.steps
         plan = eng.plan_train_steps(params, grads, m, v, step_dev, [batches[k % len(batches)] for k in range(gsteps)], lr)
         plan()
+        launched[0] += gsteps
 
     def run_steps(n):
         done = 0
@@ -491,10 +498,12 @@ def main():
             while n - done >= gsteps:
                 plan()
                 done += gsteps
+                launched[0] += gsteps
         elif graph is not None:
             while n - done >= gsteps:
                 graph.replay()
                 done += gsteps
+                launched[0] += gsteps
         run_group(0, n - done)
 
     def sweep():
@@ -534,7 +543,7 @@ def main():
     # ---- A/B (never `value`): the same workload through the drop-in per-sample step, vaek_train_step (two launches per step:
     # the fused forward/backward chain + finalize/Adam), captured and timed the same way -- what `value` was in round 1
     per_sample = None
-    if use_pipe and world == 1:
+    if use_pipe and world == 1 and not args.only_main:
         gs2 = max(2, min(gsteps if gsteps > 0 else 20, 192))
         p2, g2, m2, v2 = params.clone(), eng.new_flat(eng.grad_len), m.clone(), v.clone()
         s2 = step_dev.clone()
@@ -661,7 +670,9 @@ def main():
     # batch n+1 rides in the finalize launch of step n (vaek_train_step_gen), all inside the hipGraph
     fresh = None
     kind = {"linear_gaussian": 0, "sigmoid": 1, "sphere": 2}[w["dataset"]]
-    if world == 1 and use_pipe and eng.supports_train_steps_gen(kind):
+    if args.only_main:
+        pass
+    elif world == 1 and use_pipe and eng.supports_train_steps_gen(kind):
         # the loop body of model.py:221-222 as run.py --fast_loop runs it (trainer.GraphLoop): vaek_train_steps_gen, every step's
         # batch drawn inside the persistent launch (same Philox streams as vaek_make_batch), nothing read from HBM, no graph
         A = torch.randn(w["dd"], w["did"], generator=torch.Generator().manual_seed(2)).to(device).contiguous() if kind == 0 else None
@@ -729,6 +740,7 @@ def main():
             "metric": "ELBO train-step samples/sec", "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "steps_launched_total": launched[0],
             "timed_regions": {"count": len(regions), "steps_each": args.steps, "median_ms_per_step": elapsed / args.steps * 1e3,
                               "min_ms_per_step": min(regions) / args.steps * 1e3, "max_ms_per_step": max(regions) / args.steps * 1e3,
                               "note": "value = the median region; each region = exactly --steps train steps between barrier + synchronize"},
