@@ -246,6 +246,28 @@ static int generic_grads(vaek_ctx* c, const float* params, int32_t* step_dev, co
     float* y_lin = at<float>(ws, c->dec.act_off.back());
     const float* eps_param = c->off_eps >= 0 ? params + c->off_eps : nullptr;
     const Layer& last = c->dec.layers.back();
+    if (c->lwd) {
+        // wide linear decoder: x and z2 read ONCE for the decoder's forward, the ELBO pass, dL/d samples and the decoder's kernel
+        // gradient (linear_wide.hip); dL/d x_hat never exists in memory
+        const float* wd = params + last.w_off;
+        float* slabs = at<float>(ws, c->ws_slabs);
+        float* part = at<float>(ws, c->ws_eblk);
+        float* gpart = at<float>(ws, c->ws_lwd);
+        if ((rc = launch_lwd(samples, wd, wd + (int64_t)last.n_in * last.n_out, x, z2, eps_param, c->cfg.eps_cli, inv_bt, gpart, slabs + last.w_off,
+                             slab_stride(c), part, c->B, c->D, c->L, c->lwd_rb, st)))
+            return rc;
+        if ((rc = launch_lwd_elbo_reduce(part, last.S * (c->D / 256), mu, at<float>(ws, c->ws_epart), c->B, c->L, c->Se, c->rows_per_esplit, step_dev, st)))
+            return rc;
+        if (sink) {
+            const int64_t cnt = (int64_t)(last.n_in + 1) * last.n_out;
+            if ((rc = launch_sum_slabs(slabs + last.w_off, slab_stride(c), last.S, sink->grads + last.w_off, cnt, st))) return rc;
+            VAEK_HIP_CHECK(hipEventRecord((hipEvent_t)sink->events[sink->next++], st));
+        }
+        float* dsamp = at<float>(ws, c->ws_dsamp);
+        if ((rc = launch_lwd_reparam_bwd(gpart, c->D / 256, dsamp, mu, z1, at<float>(ws, c->ws_rpart), c->B, c->L, c->Se, c->rows_per_esplit, inv_bt, st)))
+            return rc;
+        return net_backward(c, c->enc, params, x, dsamp, ws, nullptr, false, st, sink);
+    }
     if (!sig && (c->dec.b16 || !use_bf16(c, last.n_in, last.n_out))) {
         // one decoder, exact f32 output layer: the ELBO's elementwise pass runs in that layer's epilogue -- its output never
         // goes to HBM, dL/dx_hat lands where the backward pass expects it
@@ -432,6 +454,15 @@ int vaek_ctx_create(const vaek_config* cfg, vaek_ctx** out) {
             sk_part = std::max(sk_part, sk_partial_bytes(d, H, l->S));
         }
     }
+    // wide linear decoder (BASELINE config 4): one fused kernel for its forward, the ELBO pass and both backward products; its
+    // [kernel | bias] gradient comes in one slab per ROW BLOCK of that kernel's grid
+    c->lwd = !cfg->force_generic && !cfg->sigmoid_decoder && cfg->n_dec_hidden == 0 && !c->dec.b16 && lwd_supported(c->B, c->D, c->L) &&
+             !(cfg->dtype == VAEK_BF16 && use_bf16(c, c->L, c->D));
+    if (c->lwd) {
+        Layer& l = c->dec.layers.back();
+        c->lwd_rb = lwd_row_block(c->B, c->D, c->n_cu);
+        l.rows_per_split = c->lwd_rb; l.S = (c->B + c->lwd_rb - 1) / c->lwd_rb;
+    }
     c->S = 1; c->rows_per_split = c->B;
     for (const Net* net : {&c->enc, &c->dec, &c->sig})
         for (const auto& l : net->layers) if (l.S > c->S) { c->S = l.S; c->rows_per_split = l.rows_per_split; }
@@ -461,6 +492,7 @@ int vaek_ctx_create(const vaek_config* cfg, vaek_ctx** out) {
     c->ws_sk16 = off; off = align_up(off + (size_t)sk_elems * sizeof(__bf16), 256);
     c->ws_skpart = off; off = align_up(off + sk_part, 256);
     c->ws_lin = off; off = align_up(off + lin_steps_workspace_bytes(c), 256);
+    c->ws_lwd = off; off = align_up(off + (c->lwd ? lwd_gpart_bytes(c->B, c->D, c->L) : 0), 256);
     c->ws_total = off;
     *out = c;
     return VAEK_OK;

@@ -103,7 +103,8 @@ struct vaek_ctx {
     int S, rows_per_split, Se, rows_per_esplit;
     bool fused;                      // fused small-model path available and selected
     // workspace layout (bytes)
-    size_t ws_samples, ws_dsamp, ws_gbuf0, ws_gbuf1, ws_slabs, ws_epart, ws_epart_blk, ws_rpart, ws_eblk, ws_fused, ws_wb16, ws_sk16, ws_skpart, ws_lin, ws_total;
+    size_t ws_samples, ws_dsamp, ws_gbuf0, ws_gbuf1, ws_slabs, ws_epart, ws_epart_blk, ws_rpart, ws_eblk, ws_fused, ws_wb16, ws_sk16, ws_skpart, ws_lin, ws_lwd, ws_total;
+    bool lwd = false; int lwd_rb = 0;           // wide linear decoder: fused forward / ELBO / backward (linear_wide.hip), rows per row block
     int max_width;
     int n_cu;
     vaek::Comm comm;
@@ -295,6 +296,16 @@ int lin_train_steps(vaek_ctx* c, float* params, float* grads, float* m, float* v
                     const float* const* z1s, const float* const* z2s, int n_steps, float lr, void* ws, hipStream_t st);
 int lin_steps_status(vaek_ctx* c, void* ws, int* gave_up);
 bool lin_steps_gen_supported(const vaek_ctx* c, int kind);
+// ---- linear_wide.hip: fused forward / ELBO / backward of a wide linear decoder (BASELINE config 4) ---------------------------
+bool lwd_supported(int B, int D, int L);
+int lwd_row_block(int B, int D, int n_cu);
+size_t lwd_gpart_bytes(int B, int D, int L);
+int launch_lwd(const float* samples, const float* Wd, const float* bd, const float* x, const float* z2, const float* eps_param, float eps_cli,
+               float inv_bt, float* gpart, float* slab0, int64_t slab_stride, float* part, int B, int D, int L, int RB, hipStream_t st);
+int launch_lwd_reparam_bwd(const float* gpart, int ncb, float* dsamp, const float* mu, const float* z1, float* partial, int rows, int L, int S,
+                           int rows_per_split, float inv_bt, hipStream_t st);
+int launch_lwd_elbo_reduce(const float* part, int nblk, const float* mu, float* partial, int rows, int L, int S, int rows_per_split,
+                           int32_t* step_dev, hipStream_t st);
 bool lin_moments_supported(const vaek_ctx* c);
 size_t lin_moment_len(const vaek_ctx* c);
 int lin_moments(vaek_ctx* c, const float* x, const float* z1, const float* z2, double* M_out, void* ws, hipStream_t st);
