@@ -256,15 +256,14 @@ static int generic_grads(vaek_ctx* c, const float* params, int32_t* step_dev, co
         if ((rc = launch_lwd(samples, wd, wd + (int64_t)last.n_in * last.n_out, x, z2, eps_param, c->cfg.eps_cli, inv_bt, gpart, slabs + last.w_off,
                              slab_stride(c), part, c->B, c->D, c->L, c->lwd_rb, st)))
             return rc;
-        if ((rc = launch_lwd_elbo_reduce(part, last.S * (c->D / 256), mu, at<float>(ws, c->ws_epart), c->B, c->L, c->Se, c->rows_per_esplit, step_dev, st)))
-            return rc;
         if (sink) {
             const int64_t cnt = (int64_t)(last.n_in + 1) * last.n_out;
             if ((rc = launch_sum_slabs(slabs + last.w_off, slab_stride(c), last.S, sink->grads + last.w_off, cnt, st))) return rc;
             VAEK_HIP_CHECK(hipEventRecord((hipEvent_t)sink->events[sink->next++], st));
         }
         float* dsamp = at<float>(ws, c->ws_dsamp);
-        if ((rc = launch_lwd_reparam_bwd(gpart, c->D / 256, dsamp, mu, z1, at<float>(ws, c->ws_rpart), c->B, c->L, c->Se, c->rows_per_esplit, inv_bt, st)))
+        if ((rc = launch_lwd_second(gpart, c->D / 256, dsamp, mu, z1, at<float>(ws, c->ws_rpart), c->B, c->L, c->Se, c->rows_per_esplit, inv_bt, part,
+                                    last.S * (c->D / 256), at<float>(ws, c->ws_epart), step_dev, st)))
             return rc;
         return net_backward(c, c->enc, params, x, dsamp, ws, nullptr, false, st, sink);
     }

@@ -43,7 +43,8 @@ struct LwdArgs {
     int B, D, L, RB, ncb;
 };
 
-__global__ __launch_bounds__(WT, 2) void lwd_kernel(const LwdArgs a) {
+template <int KLT>          // k-steps over the latent dimension held in registers: 5 (L <= 20) or 8 (L <= 31)
+__global__ __launch_bounds__(WT, 4) void lwd_kernel(const LwdArgs a) {       // two workgroups per CU: their barriers and LDS phases interleave
     extern __shared__ __attribute__((aligned(16))) char lwd_smem[];
     float* sS = reinterpret_cast<float*>(lwd_smem);                      // [2][16][WLP] samples of the sub-slab (+ ones column at l = L)
     float* gB = sS + 2 * WSR * WLP;                                      // [2][8 waves][32][WGS] g^T partials
@@ -51,20 +52,20 @@ __global__ __launch_bounds__(WT, 2) void lwd_kernel(const LwdArgs a) {
     float* red = tT + WW * 2 * WSR * WTS;                                // [8][2]
     const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, j = lane & 15, g = lane >> 4;
     const int cb = blockIdx.x % a.ncb, rb = blockIdx.x / a.ncb;
-    const int D = a.D, L = a.L, KL = (L + 3) >> 2;
+    const int D = a.D, L = a.L;
     const int col0 = cb * WDC + wave * WWC;
     const long long row_lo = (long long)rb * a.RB, row_hi = min((long long)a.B, row_lo + a.RB);
     const int nsub = (int)((row_hi - row_lo + WSR - 1) / WSR);
     const float eps = a.eps_param ? a.eps_param[0] * a.eps_cli : a.eps_cli;
     const float inv_var = expf(-eps), sigma = expf(0.5f * eps), dscale = inv_var * a.inv_bt;
     // ---- the wave's slice of the weights, as MFMA A operands --------------------------------------------------------------------
-    float aY[2][8];      // x_hat^T: tile t2 row d = col0 + 16 t2 + j, k-step kk: l = 4 kk + g
+    float aY[2][KLT];    // x_hat^T: tile t2 row d = col0 + 16 t2 + j, k-step kk: l = 4 kk + g
     float aG[2][8];      // g^T: row l = 16 lt + j, k index (t2, r): d = col0 + 16 t2 + 4 g + r
     float bdv[2][4];     // bias in the accumulator layout: d = col0 + 16 t2 + 4 g + r
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
+        for (int kk = 0; kk < KLT; ++kk) {
             const int l = 4 * kk + g;
             aY[t2][kk] = l < L ? a.Wd[(long long)min(l, L - 1) * D + col0 + 16 * t2 + j] : 0.f;
         }
@@ -85,13 +86,16 @@ __global__ __launch_bounds__(WT, 2) void lwd_kernel(const LwdArgs a) {
         for (int t2 = 0; t2 < 2; ++t2) accW[lt][t2] = f32x4{0.f, 0.f, 0.f, 0.f};
     float e_mse = 0.f, e_deps = 0.f;
     // ---- staging of a sub-slab's samples: thread -> (s = t / 32, l = t % 32); ones at l == L (the bias row of [samples | 1]) -------
-    auto stage = [&](int i) __attribute__((always_inline)) {
+    // (two steps: the value is LOADED one sub-slab before it is written to LDS -- written right behind its load, every sub-slab
+    // waited out a global-memory round trip, and drained the x / z2 prefetch with it)
+    auto stage_load = [&](int i) __attribute__((always_inline)) -> float {
         const int s = t >> 5, l = t & 31;
         const long long row = row_lo + (long long)i * WSR + s;
-        float v = 0.f;
-        if (i < nsub && row < row_hi) v = l < L ? a.samples[row * L + l] : (l == L ? 1.f : 0.f);
-        sS[((i & 1) * WSR + s) * WLP + l] = v;
+        const bool in = i < nsub && row < row_hi;
+        const float v = a.samples[min(row, row_hi - 1) * L + min(l, L - 1)];       // unconditional, clamped
+        return in ? (l < L ? v : (l == L ? 1.f : 0.f)) : 0.f;
     };
+    auto stage_put = [&](int i, float v) __attribute__((always_inline)) { sS[((i & 1) * WSR + (t >> 5)) * WLP + (t & 31)] = v; };
     auto load_xz = [&](int i, f32x4 (&xv)[2], f32x4 (&zv)[2]) __attribute__((always_inline)) {
         const long long row = min(row_lo + (long long)i * WSR + j, row_hi - 1);       // (clamped: masked below)
 #pragma unroll
@@ -101,26 +105,44 @@ __global__ __launch_bounds__(WT, 2) void lwd_kernel(const LwdArgs a) {
             zv[t2] = *reinterpret_cast<const f32x4*>(a.z2 + o);
         }
     };
+    // fixed-order sum of the 8 waves' g^T partials of sub-slab i -> this column block's partial of g
+    auto gsum = [&](int i) __attribute__((always_inline)) {
+        for (int o = t; o < WSR * L; o += WT) {
+            const int s = o / L, l = o - s * L;
+            const long long row = row_lo + (long long)i * WSR + s;
+            if (row < row_hi) {
+                const float* Gs = gB + (i & 1) * WW * 32 * WGS + l * WGS + s;
+                float v[WW];
+#pragma unroll
+                for (int w = 0; w < WW; ++w) v[w] = Gs[w * 32 * WGS];
+                float sum = v[0];
+#pragma unroll
+                for (int w = 1; w < WW; ++w) sum += v[w];
+                a.gpart[((long long)cb * a.B + row) * L + l] = sum;
+            }
+        }
+    };
     f32x4 xv[2], zv[2], xn[2], zn[2];
-    stage(0);
+    stage_put(0, stage_load(0));
+    float sv = stage_load(1);
     load_xz(0, xv, zv);
     __syncthreads();
     for (int i = 0; i < nsub; ++i) {
-        stage(i + 1);
+        stage_put(i + 1, sv);
+        sv = stage_load(i + 2);
         if (i + 1 < nsub) load_xz(i + 1, xn, zn);
         const float* S = sS + (i & 1) * WSR * WLP;
         const bool valid = row_lo + (long long)i * WSR + j < row_hi;
         // ---- x_hat^T, the elementwise pass, dy^T ---------------------------------------------------------------------------
-        float bS[8];
+        float bS[KLT];
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) bS[kk] = kk < KL ? S[j * WLP + 4 * kk + g] : 0.f;
+        for (int kk = 0; kk < KLT; ++kk) bS[kk] = S[j * WLP + 4 * kk + g];       // (columns l >= L of the staged samples are zeros or the ones column, which meets a zero weight)
         f32x4 dy[2];
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
-                if (kk < KL) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aY[t2][kk], bS[kk], acc, 0, 0, 0);
+            for (int kk = 0; kk < KLT; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aY[t2][kk], bS[kk], acc, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float z = zv[t2][r];
@@ -159,18 +181,7 @@ __global__ __launch_bounds__(WT, 2) void lwd_kernel(const LwdArgs a) {
                 for (int t2 = 0; t2 < 2; ++t2) accW[lt][t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(aS[lt], bT[t2], accW[lt][t2], 0, 0, 0);
         }
         __syncthreads();             // the sub-slab's g^T partials are in LDS; the next sub-slab's samples are staged
-        // ---- fixed-order sum of the 8 waves' g^T partials -> this column block's partial of g ------------------------------------
-        for (int o = t; o < WSR * L; o += WT) {
-            const int s = o / L, l = o - s * L;
-            const long long row = row_lo + (long long)i * WSR + s;
-            if (row < row_hi) {
-                const float* Gs = gB + (i & 1) * WW * 32 * WGS + l * WGS + s;
-                float sum = Gs[0];
-#pragma unroll
-                for (int w = 1; w < WW; ++w) sum += Gs[w * 32 * WGS];
-                a.gpart[((long long)cb * a.B + row) * L + l] = sum;
-            }
-        }
+        gsum(i);
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) { xv[t2] = xn[t2]; zv[t2] = zn[t2]; }
     }
@@ -198,34 +209,6 @@ __global__ __launch_bounds__(WT, 2) void lwd_kernel(const LwdArgs a) {
     }
 }
 
-// dsamp = sum over the column blocks of g's partials (fixed order) + mu / B, and the partial sums of dsamp . z1 for d logvar_e:
-// reparam_bwd_kernel (elbo.hip) with its input in ncb pieces
-__global__ __launch_bounds__(256) void lwd_reparam_bwd_kernel(const float* gpart, int ncb, float* dsamp, const float* mu, const float* z1,
-                                                              float* partial, int rows, int L, int rows_per_split, float inv_bt) {
-    extern __shared__ float sh[];   // 256 floats
-    const int s = blockIdx.x;
-    const int r0 = s * rows_per_split, r1 = min(rows, r0 + rows_per_split);
-    const int G = 256 / L;
-    const int col = threadIdx.x % L, grp = threadIdx.x / L;
-    float acc = 0.f;
-    if (grp < G) {
-        for (int r = r0 + grp; r < r1; r += G) {
-            const long long o = (long long)r * L + col;
-            float d = gpart[o];
-            for (int c = 1; c < ncb; ++c) d += gpart[(long long)c * rows * L + o];
-            acc += d * z1[o];
-            dsamp[o] = d + mu[o] * inv_bt;
-        }
-    }
-    sh[threadIdx.x] = grp < G ? acc : 0.f;
-    __syncthreads();
-    if (threadIdx.x < L) {
-        float t = 0.f;
-        for (int g2 = 0; g2 < G; ++g2) t += sh[g2 * L + threadIdx.x];
-        partial[(long long)s * L + threadIdx.x] = t;
-    }
-}
-
 // Sum over a 256-thread block; result valid in thread 0 (as elbo.hip's)
 __device__ __forceinline__ float lwd_block_sum(float v, float* red) {
 #pragma unroll
@@ -238,20 +221,51 @@ __device__ __forceinline__ float lwd_block_sum(float v, float* red) {
         for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += red[i];
     return r;
 }
-// the ELBO partials elbo_kernel would have written (partial[s] = {mse, mu^2, d eps, 0} per split): split 0 carries the block sums
-// of lwd_kernel (fixed order), every split the mu^2 of its rows
-__global__ __launch_bounds__(256) void lwd_elbo_reduce_kernel(const float* part, int nblk, const float* mu, float* partial, int rows, int L,
-                                                              int rows_per_split, int32_t* step_dev) {
-    __shared__ float red[8];
+// The second stage, one launch, split s = rows [r0, r1):
+//   * dsamp = sum over the column blocks of g's partials (fixed order) + mu / B, and the partial sums of dsamp . z1 for d logvar_e:
+//     reparam_bwd_kernel (elbo.hip) with its input in ncb pieces;
+//   * the ELBO partials elbo_kernel would have written (epartial[s] = {mse, mu^2, d eps, 0}): every split the mu^2 of its rows,
+//     split 0 on top the block sums of lwd_kernel (fixed order) -- and the Adam step counter.
+__global__ __launch_bounds__(256) void lwd_second_kernel(const float* gpart, int ncb, float* dsamp, const float* mu, const float* z1,
+                                                         float* partial, int rows, int L, int rows_per_split, float inv_bt,
+                                                         const float* part, int nblk, float* epartial, int32_t* step_dev) {
+    extern __shared__ float sh[];   // 256 + 8 floats
+    float* red = sh + 256;
     const int s = blockIdx.x;
-    const long long r0 = (long long)s * rows_per_split, r1 = min((long long)rows, r0 + rows_per_split);
-    float mse = 0.f, deps = 0.f, musq = 0.f;
+    const int r0 = s * rows_per_split, r1 = min(rows, r0 + rows_per_split);
+    const int G = 256 / L;
+    const int col = threadIdx.x % L, grp = threadIdx.x / L;
+    float acc = 0.f, musq = 0.f;
+    if (grp < G) {
+        for (int r = r0 + grp; r < r1; r += G) {
+            const long long o = (long long)r * L + col, cs = (long long)rows * L;
+            float d = 0.f;
+            for (int c0 = 0; c0 < ncb; c0 += 16) {         // 16 loads in flight, then their sum in block order
+                float v[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) v[c] = gpart[(long long)min(c0 + c, ncb - 1) * cs + o];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) d += c0 + c < ncb ? v[c] : 0.f;
+            }
+            const float mv = mu[o];
+            acc += d * z1[o];
+            musq += mv * mv;
+            dsamp[o] = d + mv * inv_bt;
+        }
+    }
+    sh[threadIdx.x] = grp < G ? acc : 0.f;
+    __syncthreads();
+    if (threadIdx.x < L) {
+        float t = 0.f;
+        for (int g2 = 0; g2 < G; ++g2) t += sh[g2 * L + threadIdx.x];
+        partial[(long long)s * L + threadIdx.x] = t;
+    }
+    float mse = 0.f, deps = 0.f;
     if (s == 0)
         for (int k = threadIdx.x; k < nblk; k += blockDim.x) { mse += part[2 * k]; deps += part[2 * k + 1]; }
-    for (long long e = r0 * L + threadIdx.x; e < r1 * L; e += blockDim.x) { const float m = mu[e]; musq += m * m; }
     const float t_mse = lwd_block_sum(mse, red), t_deps = lwd_block_sum(deps, red), t_musq = lwd_block_sum(musq, red);
     if (threadIdx.x == 0) {
-        float* p = partial + (long long)s * 4;
+        float* p = epartial + (long long)s * 4;
         p[0] = t_mse; p[1] = t_musq; p[2] = t_deps; p[3] = 0.f;
         if (s == 0 && step_dev) step_dev[0] += 1;
     }
@@ -261,7 +275,7 @@ __global__ __launch_bounds__(256) void lwd_elbo_reduce_kernel(const float* part,
 bool lwd_supported(int B, int D, int L) { return D >= 1024 && D % WDC == 0 && L >= 1 && L <= 31 && B >= 256; }
 // rows per row block: the grid (row blocks x column blocks) should be about one workgroup per CU
 int lwd_row_block(int B, int D, int n_cu) {
-    const int ncb = D / WDC, nrb = std::max(1, n_cu / ncb);
+    const int ncb = D / WDC, nrb = std::max(1, 2 * n_cu / ncb);      // two workgroups per CU
     return std::max(WSR, (int)(((long long)B + nrb - 1) / nrb + WSR - 1) / WSR * WSR);
 }
 size_t lwd_gpart_bytes(int B, int D, int L) { return (size_t)(D / WDC) * B * L * sizeof(float); }
@@ -277,26 +291,22 @@ int launch_lwd(const float* samples, const float* Wd, const float* bd, const flo
     VAEK_HIP_CHECK(hipGetDevice(&dev));
     static thread_local unsigned char attr_set[64] = {};
     if (!attr_set[dev & 63]) {
-        VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)lwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)lwd_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)lwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set[dev & 63] = 1;
     }
     ProfScope ps("lwd_decoder_fwd_bwd", st);
-    launch_k(ps, lwd_kernel, dim3((unsigned)(nrb * a.ncb)), dim3(WT), lds, st, a);
+    if (L <= 20) launch_k(ps, lwd_kernel<5>, dim3((unsigned)(nrb * a.ncb)), dim3(WT), lds, st, a);
+    else launch_k(ps, lwd_kernel<8>, dim3((unsigned)(nrb * a.ncb)), dim3(WT), lds, st, a);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
 }
-int launch_lwd_reparam_bwd(const float* gpart, int ncb, float* dsamp, const float* mu, const float* z1, float* partial, int rows, int L, int S,
-                           int rows_per_split, float inv_bt, hipStream_t st) {
-    if (L > 256) { set_error("lwd reparam backward: latent_dim %d > 256", L); return VAEK_ERR_INVALID; }
-    ProfScope ps("lwd_reparam_bwd", st);
-    launch_k(ps, lwd_reparam_bwd_kernel, dim3(S), dim3(256), 256 * sizeof(float), st, gpart, ncb, dsamp, mu, z1, partial, rows, L, rows_per_split, inv_bt);
-    VAEK_HIP_CHECK(hipGetLastError());
-    return VAEK_OK;
-}
-int launch_lwd_elbo_reduce(const float* part, int nblk, const float* mu, float* partial, int rows, int L, int S, int rows_per_split,
-                           int32_t* step_dev, hipStream_t st) {
-    ProfScope ps("lwd_elbo_reduce", st);
-    launch_k(ps, lwd_elbo_reduce_kernel, dim3(S), dim3(256), 0, st, part, nblk, mu, partial, rows, L, rows_per_split, step_dev);
+int launch_lwd_second(const float* gpart, int ncb, float* dsamp, const float* mu, const float* z1, float* partial, int rows, int L, int S,
+                      int rows_per_split, float inv_bt, const float* part, int nblk, float* epartial, int32_t* step_dev, hipStream_t st) {
+    if (L > 256) { set_error("lwd second stage: latent_dim %d > 256", L); return VAEK_ERR_INVALID; }
+    ProfScope ps("lwd_reparam_bwd_elbo_reduce", st);
+    launch_k(ps, lwd_second_kernel, dim3(S), dim3(256), 264 * sizeof(float), st, gpart, ncb, dsamp, mu, z1, partial, rows, L, rows_per_split, inv_bt,
+             part, nblk, epartial, step_dev);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
 }

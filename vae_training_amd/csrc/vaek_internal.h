@@ -302,10 +302,8 @@ int lwd_row_block(int B, int D, int n_cu);
 size_t lwd_gpart_bytes(int B, int D, int L);
 int launch_lwd(const float* samples, const float* Wd, const float* bd, const float* x, const float* z2, const float* eps_param, float eps_cli,
                float inv_bt, float* gpart, float* slab0, int64_t slab_stride, float* part, int B, int D, int L, int RB, hipStream_t st);
-int launch_lwd_reparam_bwd(const float* gpart, int ncb, float* dsamp, const float* mu, const float* z1, float* partial, int rows, int L, int S,
-                           int rows_per_split, float inv_bt, hipStream_t st);
-int launch_lwd_elbo_reduce(const float* part, int nblk, const float* mu, float* partial, int rows, int L, int S, int rows_per_split,
-                           int32_t* step_dev, hipStream_t st);
+int launch_lwd_second(const float* gpart, int ncb, float* dsamp, const float* mu, const float* z1, float* partial, int rows, int L, int S,
+                      int rows_per_split, float inv_bt, const float* part, int nblk, float* epartial, int32_t* step_dev, hipStream_t st);
 bool lin_moments_supported(const vaek_ctx* c);
 size_t lin_moment_len(const vaek_ctx* c);
 int lin_moments(vaek_ctx* c, const float* x, const float* z1, const float* z2, double* M_out, void* ws, hipStream_t st);
