@@ -1,6 +1,8 @@
 """-m gpu: the convolution kernels of the convolutional VAE (BASELINE config 5; no reference counterpart -- DESIGN.md 3.4) against
 the float64 oracle's layer functions (oracle/conv_vae_oracle.py) on float32-rounded inputs.  bf16 matrix-core products with
 float32 accumulation: the bf16 Dense path's envelope (1e-2 of the output's max-abs; measured ~3e-3), not the 1e-5 contract."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -416,3 +418,42 @@ def test_conv_vae_train_steps_reduce_the_loss_like_the_oracle():
     got, want = np.array(got), np.array(want)
     assert int(step.item()) == 6 and got[-1] < got[0]
     assert np.max(np.abs(got - want) / np.abs(want)) <= 1e-2, (got, want)
+
+
+def test_conv_vae_at_the_benched_size_is_repeatable_and_shard_additive():
+    """B = 4 096 rows per GPU with config 5's widths -- the size bench.py --workload C5 times; far beyond what the float64 oracle
+    finishes in seconds, so the checks are size-independent properties: the gradient is bitwise repeatable, and two half-batch
+    shards evaluated with the GLOBAL divisor (world = 2) sum to the full-batch gradient within 1e-4 of each leaf's max-abs
+    (networks.py:97-98: the loss is a batch mean, so the gradient is additive over row shards)."""
+    from vae_training_amd.conv_vae import ConvVAE
+    B, S, widths, L = 4096, 64, (32, 64, 128, 256), 32
+    g = torch.Generator(device="cpu").manual_seed(3)
+    full = ConvVAE(B, S, widths, L, -3.0, True)
+    params = full.new_flat()
+    for name, (off, shape) in full.leaves.items():
+        if name.endswith("kernel"):
+            fan = 16 * shape[2] if "Conv" in name and "ConvT" not in name else (4 * shape[3] if "ConvT" in name else shape[0])
+            full.view(params, name).copy_((torch.randn(*shape, generator=g) / math.sqrt(fan)).cuda())
+        elif name == "epsilon":
+            full.view(params, name).fill_(1.0)
+    x = torch.rand(B, S, S, 1, generator=g).cuda(); z1 = torch.randn(B, L, generator=g).cuda(); z2 = torch.randn(B, S, S, 1, generator=g).cuda()
+    g1, g2 = full.new_flat(), full.new_flat()
+    o1 = full.loss_and_grad(params, g1, x, z1, z2).clone()
+    o2 = full.loss_and_grad(params, g2, x, z1, z2).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(g1, g2) and torch.equal(o1, o2) and bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
+    half = ConvVAE(B // 2, S, widths, L, -3.0, True, world=2)
+    acc = torch.zeros_like(g1, dtype=torch.float64)
+    loss = 0.0
+    for w in range(2):
+        s = slice(w * B // 2, (w + 1) * B // 2)
+        gs = half.new_flat()
+        o = half.loss_and_grad(params, gs, x[s].contiguous(), z1[s].contiguous(), z2[s].contiguous())
+        acc += gs.double(); loss += float(o[0])
+    assert abs(loss - float(o1[0])) <= 1e-5 * abs(float(o1[0]))
+    worst = {}
+    for name, (off, shape) in full.leaves.items():
+        k = math.prod(shape)
+        a, b = acc[off:off + k], g1[off:off + k].double()
+        worst[name] = float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    assert max(worst.values()) <= 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
