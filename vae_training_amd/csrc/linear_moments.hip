@@ -17,7 +17,8 @@
 // What it buys.  The streaming pass over the batch (11.5 MB at the metric's size, the whole algorithmic traffic) no longer
 // depends on the parameters, so nothing couples the 256 workgroups of a step to the previous step's all-reduce -> Adam ->
 // broadcast: the two-kernel step (fused_mfma.hip + fused_finalize) spends most of its 13 us waiting on exactly that chain.
-// Here launch n carries three roles at once:
+// Here launch n carries three roles at once (the persistent form below: wave-specialised streamers, the updater on the float64
+// matrix cores -- DESIGN.md 3.0):
 //     streamers   (one per 256-sample tile)  batch n:   x, z1, z2 tiles land in LDS by global_load_lds, then
 //                 M_tile = U^T U on v_mfma_f32_16x16x4_f32 (exact f32 fmaf chains; upper block triangle only) -> one
 //                 partial image per workgroup.  No weights, no elementwise pass, no transposition (the k axis of the MFMA
@@ -33,7 +34,8 @@
 // dispatcher does with residency, and every poll is bounded (status word, vaek_train_steps_status).  What it buys on top:
 // no launch boundary and no cold start per step (the updater's instruction stream and parameters stay on one CU).
 //
-// Numerics: M accumulates exact-f32 products in chains of 64 samples (one wave's 16 MFMA k-steps), summed further in
+// Numerics: M accumulates exact-f32 products in chains of 72 samples (one multiplying wave's 18 MFMA k-steps at the metric's
+// 288-row tile; 36 in the launch-per-step form), summed further in
 // float64; everything downstream is float64 until the final rounding of each gradient to float32.  Against the float64
 // oracle the loss sits at ~1e-7 relative (tests/test_gpu_steps.py), like the sample-by-sample kernels -- but it is a
 // different summation order, so this path is NOT bitwise comparable with vaek_train_step.
