@@ -236,9 +236,11 @@ int vaek_supports_train_steps(const vaek_ctx* ctx, int32_t* yes);
 int vaek_train_steps(vaek_ctx* ctx, float* params, float* grads, float* m, float* v, int32_t* step_dev,
                      const float* const* xs, const float* const* z1s, const float* const* z2s, int32_t n_steps, float lr,
                      void* workspace, void* stream);
-/* Synchronous (reads one word back): *gave_up != 0 if a bounded in-launch wait of vaek_train_steps' persistent form ever expired
- * (the results of that call are then invalid).  The word says which wait: 0x80000000 | role << 28 (1 the updater, 2 a reducer)
- * | batch index within the launch << 16 | the arrival count it last saw. */
+/* Synchronous (reads one word back): *gave_up != 0 if a bounded in-launch wait of vaek_train_steps' / vaek_train_steps_gen's persistent
+ * form has expired in ANY launch since the last call of this function (the results since then are invalid).  The word is STICKY on
+ * the device -- no launch clears it, and while it is set every wait of every later launch returns at once (the grid drains) -- and
+ * this call is read-and-clear.  It says which wait came first: 0x80000000 | role << 28 (1 the updater, 2 a reducer, 3 a reducer
+ * waiting for a peer rank's moments) | batch index within the launch << 16 | the arrival count it last saw. */
 int vaek_train_steps_status(vaek_ctx* ctx, void* workspace, int32_t* gave_up);
 /* The same N train steps with the batches DRAWN inside the launch: step k of the call (the one that takes *step_dev from t to
  * t + 1) trains on the batch vaek_make_batch(kind, A, dd, did, pad, var_added, rows = ctx.batch, row0, seed, step = t, tag)
