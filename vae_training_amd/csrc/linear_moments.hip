@@ -307,6 +307,25 @@ struct LinTileSrc {
         off = off <= last ? off : last;
         lin_glds16(src + off, slot + lds_off + idx * 1024);
     }
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // (M0 on the clobber list: it is what the LDS-DMA takes its LDS address from)
+    __device__ __forceinline__ void issue_tile(const LinTile& tl, int lw, int NLW, int lane) const {
+        auto region = [&](const char* src, long long base, long long last, int n, int lds_off) __attribute__((always_inline)) {
+            const long long b2 = base <= last ? base : last;           // (a last tile shorter than 16 bytes: every lane reads the tensor's last 16)
+            const char* sbase = src + b2;
+            const unsigned lastrel = (unsigned)(last - b2), degenerate = base <= last ? 0xffffffffu : 0u;
+            const unsigned m0_0 = (unsigned)(size_t)(lds_void_t*)(slot + lds_off);
+            for (int idx = lw; idx < n; idx += NLW) {
+                unsigned off = ((unsigned)idx * 1024u + (unsigned)lane * 16u) & degenerate;
+                off = off <= lastrel ? off : lastrel;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(sbase), "s"(m0_0 + (unsigned)idx * 1024u) : "memory", "m0");
+            }
+        };
+        region(z1, baseL, lastL, tl.nz1, 0);
+        region(x, baseD, lastD, tl.nx, tl.oX);
+        region(z2, baseD, lastD, tl.np - tl.nz1 - tl.nx, tl.oZ2);
+    }
+#pragma clang diagnostic pop
 };
 
 // the last tile of a ragged batch, after it has landed: the tensors' last floats behind their last whole 16 bytes, zeros in the
@@ -1289,23 +1308,31 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
         const bool loader = wave >= kLinCW;
         const int lw = wave - kLinCW;                                                            // loader waves: 0 .. NLW - 1
         constexpr int NLW = LNW - kLinCW;
-        const int npw = (GEN || !loader) ? 0 : (lw < tl.np ? (tl.np - lw + NLW - 1) / NLW : 0);  // this wave's pieces of a tile
+        auto share = [&](int n) { return lw < n ? (n - lw + NLW - 1) / NLW : 0; };
+        const int npw = (GEN || !loader) ? 0 : share(tl.nz1) + share(tl.nx) + share(tl.np - tl.nz1 - tl.nx);  // this wave's pieces of a tile: its share of each tensor's
         const int sw = wave < (NO / 4 + 63) / 64 ? 1 : 0;                                        // does this wave store a share of an image?
-        auto item_batch = [&](int i) { return i / per_batch; };
-        auto item_tile = [&](int i) { return sid + (i % per_batch) * S; };
+        // item i = tile sid + (i % per_batch) S of batch i / per_batch, in slot i % 3: walked by cursors (a run-time integer division
+        // costs ~40 instructions, and the loop wanted a dozen per tile)
+        struct Pos {
+            int idx, n, r, slot;
+            __device__ __forceinline__ void advance(int per_batch) { ++idx; slot = slot == 2 ? 0 : slot + 1; if (++r == per_batch) { r = 0; ++n; } }
+        };
+        auto pos_tile = [&](const Pos& q) { return sid + q.r * S; };
+        Pos p_cur{0, 0, 0, 0}, p_load{0, 0, 0, 0}, p_sig{0, 0, 0, 0};      // the item being multiplied / the next to load or draw / the next to signal
         LinTileSrc nxt;                                       // the item whose pieces are being issued
         nxt.on = false;
-        auto prepare = [&](int i) __attribute__((always_inline)) {
+        auto prepare = [&]() __attribute__((always_inline)) {             // the next item in order (p_load), which it advances
             if constexpr (!GEN) {
                 nxt.on = false;
-                if (i < items) {
-                    const int n = item_batch(i);
-                    nxt.prepare(a, tab[n], tab[kLinMaxPersist + n], tab[2 * kLinMaxPersist + n], item_tile(i), lin_smem + (i % 3) * stride);
+                if (p_load.idx < items) {
+                    const int n = p_load.n;
+                    nxt.prepare(a, tab[n], tab[kLinMaxPersist + n], tab[2 * kLinMaxPersist + n], pos_tile(p_load), lin_smem + p_load.slot * stride);
                 }
+                p_load.advance(per_batch);
             }
         };
-        auto issue_piece = [&](int k) __attribute__((always_inline)) {   // k-th piece of this wave's share of that item
-            if constexpr (!GEN) { if (!(VAEK_LIN_ABL & 8) && nxt.on && k < npw) nxt.issue(tl, lw + NLW * k, lane); }
+        auto issue_pieces = [&]() __attribute__((always_inline)) {      // this wave's share of that item
+            if constexpr (!GEN) { if (!(VAEK_LIN_ABL & 8) && nxt.on) nxt.issue_tile(tl, lw, NLW, lane); }
         };
         // GEN: the draw of item i in ROUNDS dealt to the GT = 256 threads of the loader waves.  A unit of work is a row of x or one
         // latent block (4 normals: block z = row * nzb + q holds columns 4 q .. of the row's [z1 | z2]): first the rows of x (thread =
@@ -1320,13 +1347,13 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
         // (copies: read through `src` the generator's scalars are re-fetched from the kernel-argument segment inside the loops)
         [[maybe_unused]] int g_kind = 0, g_dd = 0, g_did = 0; [[maybe_unused]] float g_noise = 0.f; [[maybe_unused]] unsigned g_tag = 0;
         if constexpr (GEN) { g_kind = src.kind; g_dd = src.dd; g_did = src.did; g_noise = src.noise_std; g_tag = src.tag; }
-        auto gen_round = [&](int i, int k) __attribute__((always_inline)) {       // loader waves only
+        auto gen_round = [&](const Pos& q, int k) __attribute__((always_inline)) {       // loader waves only: item q
             if constexpr (GEN) {
-                if (i < items && k < gen_rounds) {
+                if (q.idx < items && k < gen_rounds) {
                     const uint2 key = make_uint2((unsigned)src.seed, (unsigned)(src.seed >> 32));
-                    const long long row_lo = (long long)item_tile(i) * a.T;
-                    const unsigned step = step0 + (unsigned)item_batch(i);
-                    char* slot = lin_smem + (i % 3) * stride;
+                    const long long row_lo = (long long)pos_tile(q) * a.T;
+                    const unsigned step = step0 + (unsigned)q.n;
+                    char* slot = lin_smem + q.slot * stride;
                     auto put = [&](int z, const float (&n4)[4]) __attribute__((always_inline)) {      // latent block z of the tile
                         const int r = z / nzb, q = z - r * nzb, c0 = 4 * q;
                         const bool live = row_lo + r < a.B;
@@ -1415,17 +1442,21 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
             }
         };
         unsigned* const my_shard = a.cnt_stream + (b & (kLinShards - 1)) * kLinShardStride;
-        auto signal = [&](int i) {                            // image of item i is out (ONE lane, behind every wave's drain + a barrier)
-            if (t == 0) __hip_atomic_fetch_add(my_shard + item_batch(i) * kLinShards * kLinShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        auto signal = [&]() {                                 // the next image in order is out (ONE lane, behind every wave's drain + a barrier)
+            if (t == 0) __hip_atomic_fetch_add(my_shard + p_sig.n * kLinShards * kLinShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p_sig.advance(per_batch);
         };
         if (loader) {
-            prepare(0);
-            for (int k = 0; k < npw; ++k) issue_piece(k);
-            prepare(1);
-            for (int k = 0; k < npw; ++k) issue_piece(k);
+            prepare();
+            issue_pieces();
+            prepare();
+            issue_pieces();
             if constexpr (GEN) {
+                Pos q1 = p_load;
+                q1.advance(per_batch);
 #pragma unroll 1
-                for (int k = 0; k < 2 * gen_rounds; ++k) gen_round(k & 1, k >> 1);
+                for (int k = 0; k < 2 * gen_rounds; ++k) gen_round((k & 1) ? q1 : p_load, k >> 1);
+                p_load.advance(per_batch); p_load.advance(per_batch);
             }
         }
         [[maybe_unused]] unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, sacc_i = 0, sacc_l = 0, sacc_f = 0, sacc_m = 0, sacc_p = 0, sacc_b = 0;
@@ -1435,9 +1466,9 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
             LIN_NOWQ(s1);
             lin_barrier();                                     // ... for every wave; and everybody is done with slot (i + 2) % 3 (the scratch of i - 1)
             LIN_NOWQ(s2);
-            if (i >= 3) signal(i - 2);                         // (image 0 left at the end of iteration 0)
-            const int n = item_batch(i), tile = item_tile(i);
-            char* slot = lin_smem + (i % 3) * stride;
+            if (i >= 3) signal();                              // image i - 2 (image 0 left at the end of iteration 0)
+            const int n = p_cur.n, tile = pos_tile(p_cur), slot_off = p_cur.slot * stride;
+            char* slot = lin_smem + slot_off;
             const bool ragged = tile == a.ntiles - 1 && valid_last < a.T;
             if constexpr (!GEN) {
                 if (ragged) lin_fix_ragged(a, tl, tab[n], tab[kLinMaxPersist + n], tab[2 * kLinMaxPersist + n], tile, slot, t);
@@ -1445,23 +1476,24 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
             LIN_NOWQ(s3);
             f32x4 acc[NB * (NB + 1) / 2];
             if (!loader) {
-                lin_tile_products<NB, JT, kLinCW>(a, tl, lin_smem, (i % 3) * stride, ragged ? vr_off : v_off, c_off, acc, lane, wave, [](int) {});
+                lin_tile_products<NB, JT, kLinCW>(a, tl, lin_smem, slot_off, ragged ? vr_off : v_off, c_off, acc, lane, wave, [](int) {});
             } else if constexpr (GEN) {
 #pragma unroll 1
                 for (int k = 0; k < gen_rounds; ++k) {
                     [[maybe_unused]] unsigned long long g0 = 0, g1 = 0;
                     LIN_NOWQ(g0);
-                    gen_round(i + 2, k);
+                    gen_round(p_load, k);
                     LIN_NOWQ(g1);
 #ifdef VAEK_LIN_STAMPS
                     if (sid == 7 && gt == 0 && g_lin_stamp_buf && k < 8) g_lin_stamp_buf[200 + k] += g1 - g0;
 #endif
                 }
+                p_load.advance(per_batch);
             } else if (i > 0) {
                 // (iteration 0 issues the pieces of tile 2 only behind its early signal: the drain in front of that signal would
                 // otherwise wait for them to land)
-                prepare(i + 2);
-                for (int k = 0; k < npw; ++k) issue_piece(k);
+                prepare();
+                issue_pieces();
             }
             LIN_NOWQ(s5);
             lin_barrier();                                     // every wave has read its last operand: the slot turns into scratch
@@ -1470,23 +1502,24 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
             if (i == 0) {                                      // the launch's first image: out at once (pipeline fill), not two tiles later
                 lin_wait_vmcnt<0>();
                 lin_barrier();
-                signal(0);
+                signal();
                 if (sid == 0) { [[maybe_unused]] unsigned long long te = 0; LIN_NOWQ(te); LIN_PUT(53, te); }
                 if constexpr (!GEN) {
                     if (loader) {
-                        prepare(2);
-                        for (int k = 0; k < npw; ++k) issue_piece(k);
+                        prepare();
+                        issue_pieces();
                     }
                 }
             }
             LIN_NOWQ(s4);
             if (i + 1 < items) { sacc_i += s1 - s0; sacc_l += s2 - s1; sacc_f += s3 - s2; sacc_m += s4 - s3; sacc_p += s5 - s3; sacc_b += s6 - s5; }
             if (sid == 7) { LIN_PUT(42, sacc_i); LIN_PUT(43, sacc_l); LIN_PUT(44, sacc_f); LIN_PUT(45, sacc_m); LIN_PUT(46, (unsigned long long)items); LIN_PUT(47, sacc_p); LIN_PUT(48, sacc_b); }
+            p_cur.advance(per_batch);
         }
         lin_wait_vmcnt<0>();
         lin_barrier();
-        if (items - 2 >= 1) signal(items - 2);
-        if (items - 1 >= 1) signal(items - 1);
+        if (items - 2 >= 1) signal();
+        if (items - 1 >= 1) signal();
     }
 }
 
