@@ -47,8 +47,6 @@ if persist:
     print(f"   reducer workgroup 5 (32 of the launch's batches): waiting {t[40] / 100.0:.1f} us, reducing {t[41] / 100.0:.1f} us")
     print(f"   streamer 7 ({t[46]} work items), us per item: counted wait {t[42] / 100.0 / t[46]:.2f}, barrier {t[43] / 100.0 / t[46]:.2f}, ragged fix {t[44] / 100.0 / t[46]:.2f}, "
           f"products (pieces of a later tile issued between the k-steps) {t[47] / 100.0 / t[46]:.2f}, barrier {t[48] / 100.0 / t[46]:.2f}, cross-wave sum + store {(t[45] - t[47] - t[48]) / 100.0 / t[46]:.2f}")
-    if os.environ.get("LIN_GEN") == "1":
-        print("   streamer 7, wave 0, us per item in each draw round: " + "  ".join(f"{t[200 + k] / 100.0 / t[46]:.2f}" for k in range(6)))
     print(f"   streamers 0 / S/2 / S-1 entered the kernel at {(t[50] - t0) / 100.0:.1f} / {(t[51] - t0) / 100.0:.1f} / {(t[52] - t0) / 100.0:.1f} us, signalled batch 0 at {(t[53] - t0) / 100.0:.1f} / {(t[54] - t0) / 100.0:.1f} / {(t[55] - t0) / 100.0:.1f} us")
     print("   reducer 5, batches 0..2: woke at / done at (us): " + "  ".join(f"{(t[56 + 2 * n] - t0) / 100.0:.1f} / {(t[57 + 2 * n] - t0) / 100.0:.1f}" for n in range(3)))
     print("   batch: reduced at | updated at  (us after the updater entered its loop; last arrival of each role)")

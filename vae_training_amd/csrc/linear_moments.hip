@@ -1298,7 +1298,7 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
         const int valid_last = a.B - (a.ntiles - 1) * a.T;              // rows of a batch's last tile
         lin_write_vcol(reinterpret_cast<float*>(lin_smem + v_off), a.T, a.T, t);
         lin_write_vcol(reinterpret_cast<float*>(lin_smem + vr_off), a.T, valid_last, t);
-        if (t == 0) *reinterpret_cast<float*>(lin_smem + c_off) = 0.f;
+        if (t == 0) { *reinterpret_cast<float*>(lin_smem + c_off) = 0.f; *reinterpret_cast<unsigned*>(lin_smem + c_off + 8) = 0u; }      // the zero word; the draw's ticket counter
         __syncthreads();
         const int per_batch = sid < a.ntiles ? (a.ntiles - sid + S - 1) / S : 0, items = N * per_batch;
         // Wave roles inside a streamer: waves 0 .. 3 (one per SIMD) multiply, waves 4 .. 7 load (LDS-DMA pieces of the tile two ahead,
@@ -1337,9 +1337,11 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
         // GEN: the draw of item i in ROUNDS dealt to the GT = 256 threads of the loader waves.  A unit of work is a row of x or one
         // latent block (4 normals: block z = row * nzb + q holds columns 4 q .. of the row's [z1 | z2]): first the rows of x (thread =
         // row, ceil(T / GT) rounds), then rounds that give every thread TWO latent blocks (two independent Philox chains), then what
-        // is left, one block per thread.  Rows past the batch end are written as zeros.
+        // is left, one block per thread.  Rows past the batch end are written as zeros.  WHO draws: a unit of 64 draw threads of one
+        // round goes to whichever wave takes the next ticket (an LDS counter) -- the loading waves from the barrier on, the multiplying
+        // waves once their products are done: the draw is vector-ALU work (9 Philox blocks + Box-Muller per sample: 8.7 us per tile on
+        // four waves), the products keep a wave's matrix pipe busy for 2.2 us of it.  What a unit writes depends on the unit alone.
         constexpr int GT = NLW * 64;
-        [[maybe_unused]] const int gt = t - kLinCW * 64;
         [[maybe_unused]] const int gD = DT ? DT : a.D, gL = LT ? LT : a.L, nzb = (gL + gD + 3) / 4;
         [[maybe_unused]] const int nlat = a.T * nzb, xr = (a.T + GT - 1) / GT, npair = nlat / (2 * GT), rem = nlat - 2 * GT * npair;
         [[maybe_unused]] const int gen_rounds = xr + npair + (rem + GT - 1) / GT;
@@ -1347,7 +1349,7 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
         // (copies: read through `src` the generator's scalars are re-fetched from the kernel-argument segment inside the loops)
         [[maybe_unused]] int g_kind = 0, g_dd = 0, g_did = 0; [[maybe_unused]] float g_noise = 0.f; [[maybe_unused]] unsigned g_tag = 0;
         if constexpr (GEN) { g_kind = src.kind; g_dd = src.dd; g_did = src.did; g_noise = src.noise_std; g_tag = src.tag; }
-        auto gen_round = [&](const Pos& q, int k) __attribute__((always_inline)) {       // loader waves only: item q
+        auto gen_round = [&](const Pos& q, int k, int gt) __attribute__((always_inline)) {       // round k of item q, as draw thread gt of GT
             if constexpr (GEN) {
                 if (q.idx < items && k < gen_rounds) {
                     const uint2 key = make_uint2((unsigned)src.seed, (unsigned)(src.seed >> 32));
@@ -1441,23 +1443,40 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
                 }
             }
         };
+        [[maybe_unused]] unsigned* const ticket = reinterpret_cast<unsigned*>(lin_smem + c_off + 8);       // zeroed between two barriers before every use
+        // every wave: units of the draw of q0 (and then of q1, nitems == 2) until the tickets run out
+        auto gen_share = [&](const Pos& q0, const Pos& q1, int nitems) __attribute__((always_inline)) {
+            if constexpr (GEN) {
+                const unsigned units = (unsigned)gen_rounds * NLW, total = units * (unsigned)nitems;
+#pragma unroll 1
+                for (;;) {
+                    unsigned u = 0;
+                    if (lane == 0) u = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    u = (unsigned)__builtin_amdgcn_readfirstlane((int)u);
+                    if (u >= total) break;
+                    const bool second = u >= units;
+                    const unsigned v = second ? u - units : u;
+                    gen_round(second ? q1 : q0, (int)(v / NLW), (int)(v % NLW) * 64 + lane);
+                }
+            }
+        };
         unsigned* const my_shard = a.cnt_stream + (b & (kLinShards - 1)) * kLinShardStride;
         auto signal = [&]() {                                 // the next image in order is out (ONE lane, behind every wave's drain + a barrier)
             if (t == 0) __hip_atomic_fetch_add(my_shard + p_sig.n * kLinShards * kLinShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             p_sig.advance(per_batch);
         };
-        if (loader) {
+        if constexpr (GEN) {
+            Pos q1 = p_load;
+            q1.advance(per_batch);
+            gen_share(p_load, q1, 2);                          // items 0 and 1: every wave draws
+            p_load.advance(per_batch); p_load.advance(per_batch);
+            lin_barrier();
+            if (t == 0) *ticket = 0u;                          // (the loop's first barrier stands between this and the next ticket)
+        } else if (loader) {
             prepare();
             issue_pieces();
             prepare();
             issue_pieces();
-            if constexpr (GEN) {
-                Pos q1 = p_load;
-                q1.advance(per_batch);
-#pragma unroll 1
-                for (int k = 0; k < 2 * gen_rounds; ++k) gen_round((k & 1) ? q1 : p_load, k >> 1);
-                p_load.advance(per_batch); p_load.advance(per_batch);
-            }
         }
         [[maybe_unused]] unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, sacc_i = 0, sacc_l = 0, sacc_f = 0, sacc_m = 0, sacc_p = 0, sacc_b = 0;
         for (int i = 0; i < items; ++i) {
@@ -1475,21 +1494,11 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
             }
             LIN_NOWQ(s3);
             f32x4 acc[NB * (NB + 1) / 2];
-            if (!loader) {
-                lin_tile_products<NB, JT, kLinCW>(a, tl, lin_smem, slot_off, ragged ? vr_off : v_off, c_off, acc, lane, wave, [](int) {});
-            } else if constexpr (GEN) {
-#pragma unroll 1
-                for (int k = 0; k < gen_rounds; ++k) {
-                    [[maybe_unused]] unsigned long long g0 = 0, g1 = 0;
-                    LIN_NOWQ(g0);
-                    gen_round(p_load, k);
-                    LIN_NOWQ(g1);
-#ifdef VAEK_LIN_STAMPS
-                    if (sid == 7 && gt == 0 && g_lin_stamp_buf && k < 8) g_lin_stamp_buf[200 + k] += g1 - g0;
-#endif
-                }
+            if (!loader) lin_tile_products<NB, JT, kLinCW>(a, tl, lin_smem, slot_off, ragged ? vr_off : v_off, c_off, acc, lane, wave, [](int) {});
+            if constexpr (GEN) {
+                gen_share(p_load, p_load, 1);                  // item i + 2: the loading waves at once, the multiplying waves behind their products
                 p_load.advance(per_batch);
-            } else if (i > 0) {
+            } else if (loader && i > 0) {
                 // (iteration 0 issues the pieces of tile 2 only behind its early signal: the drain in front of that signal would
                 // otherwise wait for them to land)
                 prepare();
@@ -1497,6 +1506,7 @@ __global__ __launch_bounds__(LNT, 2) void lin_persist_kernel(const LinArgs a, co
             }
             LIN_NOWQ(s5);
             lin_barrier();                                     // every wave has read its last operand: the slot turns into scratch
+            if constexpr (GEN) { if (t == 0) *ticket = 0u; }   // (nobody takes a ticket before the next iteration's first barrier)
             LIN_NOWQ(s6);
             lin_tile_combine<NB, true, kLinCW>(acc, slot, a.partial_base + ((long long)n * a.ntiles + tile) * NO, t, wave, lane);
             if (i == 0) {                                      // the launch's first image: out at once (pipeline fill), not two tiles later
