@@ -457,10 +457,14 @@ struct HsDwArgs {
 // ch ^ (((k & 3) << 2) | ((k >> 2) & 3)): the 32 lanes of a ds_read_b64_tr_b16 half (4 k-rows x 2 blocks of 16
 // features) then cover the 256-byte bank row exactly.
 // NARROW (N <= 64): the four waves stack along M (32 rows x 64 columns each) instead of 2 x 2 -- no wave multiplies columns past N
-template <int BK, int NS, bool CONV = false, bool NARROW = false>
-__global__ __launch_bounds__(256) void hs_tn_kernel(const HsDwArgs g) {
-    constexpr int BM = 128, BN = 128, T_BYTES = BK * 256, BUF = 2 * T_BYTES;
-    constexpr int PASSES = BK / 16, P = 2 * PASSES;           // staging passes per operand tile; loads per k-tile and wave
+// BM 256 (eight waves, 4 x 2): the M side is TWO 128-feature images side by side -- 1.5 KB of operands per k-row for twice the
+// products of the 128 x 128 tile's 1 KB
+template <int BK, int NS, bool CONV = false, bool NARROW = false, int BM = 128>
+__global__ __launch_bounds__(2 * BM) void hs_tn_kernel(const HsDwArgs g) {
+    constexpr int BN = 128, T_BYTES = BK * 256, NTH = 2 * BM, AT = BM / 128, BUF = (AT + 1) * T_BYTES;
+    constexpr int PPT = BK * 16 / NTH, P = (AT + 1) * PPT;    // staging passes per 128-feature image; loads per k-tile and wave
+    constexpr int PASSES = AT * PPT;                          // ... of the A side
+    static_assert(BK * 16 % NTH == 0 && (BM == 128 || (!CONV && !NARROW)), "whole staging passes");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned tiles = g.tiles_m * g.tiles_n, nb = gridDim.x;
     unsigned id = blockIdx.x;
@@ -474,14 +478,16 @@ __global__ __launch_bounds__(256) void hs_tn_kernel(const HsDwArgs g) {
     constexpr int TI = NARROW ? 1 : 2, WROWS = NARROW ? 32 : 64;      // m-fragments per wave, rows of M per wave
     const int wm = NARROW ? wv : wv >> 1, wn = NARROW ? 0 : wv & 1;
 
-    // staging: 16 BK chunks per tile; position p -> k-row p >> 4, chunk slot p & 15
-    int a_col[PASSES], b_col[PASSES], s_row[PASSES];
+    // staging: 16 BK chunks per 128-feature image; position p -> k-row p >> 4, chunk slot p & 15; pass i of the A side belongs to
+    // image i / PPT
+    int a_col[PASSES], b_col[PPT], s_row[PPT];
 #pragma unroll
-    for (int i = 0; i < PASSES; ++i) {
-        const int p = i * 256 + t, row = p >> 4, ch = (p & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    for (int i = 0; i < PPT; ++i) {
+        const int p = i * NTH + t, row = p >> 4, ch = (p & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
         s_row[i] = row;
-        a_col[i] = min(m0 + ch * 8, g.M - 8);        // a partial last tile re-reads valid columns; those outputs are not stored
-        b_col[i] = min(n0 + ch * 8, g.N - 8);
+        b_col[i] = min(n0 + ch * 8, g.N - 8);        // a partial last tile re-reads valid columns; those outputs are not stored
+#pragma unroll
+        for (int im = 0; im < AT; ++im) a_col[im * PPT + i] = min(m0 + 128 * im + ch * 8, g.M - 8);
     }
     // CONV: this thread's chunk of 8 columns is 8 channels of ONE tap, fixed for the whole kernel
     int c_dy[PASSES], c_dx[PASSES], c_ch[PASSES];
@@ -494,6 +500,17 @@ __global__ __launch_bounds__(256) void hs_tn_kernel(const HsDwArgs g) {
     }
     auto stage = [&](int k0, int slot) {
         char* base = smem + slot * BUF;
+        if constexpr (BM != 128) {
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                const long long krow = min(k0 + s_row[i], g.rows - 1);
+#pragma unroll
+                for (int im = 0; im < AT; ++im)
+                    glds16(g.X + krow * g.ldx + a_col[im * PPT + i], base + im * T_BYTES + (i * NTH + wv * 64) * 16);
+                glds16(g.dY + krow * g.ldy + b_col[i], base + AT * T_BYTES + (i * NTH + wv * 64) * 16);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
             const long long krow = min(k0 + s_row[i], g.rows - 1);
@@ -518,10 +535,10 @@ __global__ __launch_bounds__(256) void hs_tn_kernel(const HsDwArgs g) {
         const int krow = 8 * h + 4 * u + q, xr = (q << 2) | ((2 * h + u) & 3);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int mcol = wm * WROWS + (i % TI) * 32 + 16 * g16 + 4 * p;
-            a_addr[i][u] = krow * 256 + (((mcol >> 3) ^ xr) << 4) + ((mcol >> 2) & 1) * 8;
+            const int mfull = wm * WROWS + (i % TI) * 32 + 16 * g16 + 4 * p, mcol = mfull & 127;
+            a_addr[i][u] = (mfull >> 7) * T_BYTES + krow * 256 + (((mcol >> 3) ^ xr) << 4) + ((mcol >> 2) & 1) * 8;
             const int ncol = wn * 64 + i * 32 + 16 * g16 + 4 * p;
-            b_addr[i][u] = krow * 256 + (((ncol >> 3) ^ xr) << 4) + ((ncol >> 2) & 1) * 8 + T_BYTES;
+            b_addr[i][u] = krow * 256 + (((ncol >> 3) ^ xr) << 4) + ((ncol >> 2) & 1) * 8 + AT * T_BYTES;
         }
     }
     f32x16 acc[2][2], accb[2];
@@ -549,7 +566,7 @@ __global__ __launch_bounds__(256) void hs_tn_kernel(const HsDwArgs g) {
         const int boff = slot * BUF;
         const int valid = kend - (kbeg + kt * BK);
         if (valid < BK) {                           // last k-tile of the batch: rows past the end must contribute zero
-            for (int o = t * 16; o < BUF; o += 256 * 16)
+            for (int o = t * 16; o < BUF; o += NTH * 16)
                 if (((o & (T_BYTES - 1)) >> 8) >= valid) *reinterpret_cast<uint4*>(smem + boff + o) = make_uint4(0, 0, 0, 0);
             __syncthreads();
         }
@@ -829,19 +846,22 @@ static const HsNtVariant kNt[] = {
 };
 constexpr int kNtCount = sizeof(kNt) / sizeof(kNt[0]);
 typedef void (*HsTnKernel)(const HsDwArgs);
-struct HsTnVariant { HsTnKernel fn; size_t lds; const char* name; };
+struct HsTnVariant { HsTnKernel fn; size_t lds; const char* name; int bm; };
 static const HsTnVariant kTn[] = {
-    {hs_tn_kernel<64, 2>, 2 * 2 * 64 * 256, "128x128x64 ring2"},      // 0: the first version
-    {hs_tn_kernel<32, 5>, 5 * 2 * 32 * 256, "128x128x32 ring5"},      // 1
-    {hs_tn_kernel<64, 4>, 4 * 2 * 64 * 256, "128x128x64 ring4"},      // 2: one workgroup per CU
-    {hs_tn_kernel<32, 4>, 4 * 2 * 32 * 256, "128x128x32 ring4"},      // 3
-    {hs_tn_kernel<32, 3>, 3 * 2 * 32 * 256, "128x128x32 ring3"},      // 4: three workgroups per CU
+    {hs_tn_kernel<64, 2>, 2 * 2 * 64 * 256, "128x128x64 ring2", 128},      // 0: the first version
+    {hs_tn_kernel<32, 5>, 5 * 2 * 32 * 256, "128x128x32 ring5", 128},      // 1
+    {hs_tn_kernel<64, 4>, 4 * 2 * 64 * 256, "128x128x64 ring4", 128},      // 2: one workgroup per CU
+    {hs_tn_kernel<32, 4>, 4 * 2 * 32 * 256, "128x128x32 ring4", 128},      // 3
+    {hs_tn_kernel<32, 3>, 3 * 2 * 32 * 256, "128x128x32 ring3", 128},      // 4: three workgroups per CU
+    {hs_tn_kernel<64, 2, false, false, 256>, 2 * 3 * 64 * 256, "256x128x64 ring2", 256},      // 5: eight waves, one workgroup per CU
+    {hs_tn_kernel<32, 4, false, false, 256>, 4 * 3 * 32 * 256, "256x128x32 ring4", 256},      // 6
+    {hs_tn_kernel<64, 3, false, false, 256>, 3 * 3 * 64 * 256, "256x128x64 ring3", 256},      // 7: 144 KB
 };
 constexpr int kTnCount = sizeof(kTn) / sizeof(kTn[0]);
 // -1 = by shape: 256 x 256 tiles where they still give every CU a workgroup (C3 at full size: forward 50 -> 44 us), 128 x 128
 // with three workgroups per CU otherwise; measured on the box (tools/hs_tune.py), every variant bitwise identical
 // (tests/test_gpu_bf16.py::test_bf16s_variants_are_bitwise_identical)
-int g_hs_variant_nt = -1, g_hs_variant_tn = 0;
+int g_hs_variant_nt = -1, g_hs_variant_tn = -1;
 
 template <int EPI>
 static int hs_launch_nt(const HsArgs& g, const char* label, hipStream_t st) {
@@ -887,17 +907,20 @@ int launch_hs_dw(const __bf16* x, const __bf16* dy, float* slab0, int64_t slab_s
     HsDwArgs g{};
     g.X = x; g.dY = dy; g.slab = slab0; g.rows = rows; g.M = n_in; g.N = n_out; g.ldx = n_in; g.ldy = n_out;
     g.rows_per_split = rows_per_split; g.slab_stride = slab_stride;
-    g.tiles_m = (n_in + 127) / 128; g.tiles_n = (n_out + 127) / 128;
-    const int vi = g_hs_variant_tn;
+    // -1 = by shape: 256 x 128 tiles (a quarter fewer operand bytes through L2 -> LDS per product: C3's 512 x 512 layers 75 -> 63 us)
+    // where they still give most CUs a workgroup, 128 x 128 otherwise; every variant bitwise identical for the same splits
+    const bool big = n_in % 256 == 0 && (long long)(n_in / 256) * ((n_out + 127) / 128) * S >= 192;
+    const int vi = g_hs_variant_tn >= 0 ? g_hs_variant_tn : (big ? 5 : 0);
     if (vi < 0 || vi >= kTnCount) { set_error("unknown bf16-storage dW variant %d", vi); return VAEK_ERR_INVALID; }
     const HsTnVariant& v = kTn[vi];
+    g.tiles_m = (n_in + v.bm - 1) / v.bm; g.tiles_n = (n_out + 127) / 128;
     static thread_local bool attr_set[kTnCount] = {};
     if (!attr_set[vi]) {
         VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
         attr_set[vi] = true;
     }
     ProfScope ps("gemm_bf16s_dw", st);
-    launch_k(ps, v.fn, dim3((unsigned)(g.tiles_m * g.tiles_n * S)), dim3(256), v.lds, st, g);
+    launch_k(ps, v.fn, dim3((unsigned)(g.tiles_m * g.tiles_n * S)), dim3(2 * v.bm), v.lds, st, g);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
 }
