@@ -15,7 +15,10 @@ pytestmark = pytest.mark.gpu
 # (128,): one hidden layer -> only skinny layers, exact f32 kernels.  (256, 128), (192, 64, 192): every hidden width a multiple
 # of 64 -> the bf16-STORAGE mode (gemm_bf16s.hip: bf16 activations / gradients in HBM, direct-to-LDS loads, transposed LDS
 # reads for dW).  (200, 200): widths off the 64 grid -> f32 storage with the round-1 kernels (gemm_bf16.hip).
-@pytest.mark.parametrize("hidden,B", [((128,), 700), ((256, 128), 1000), ((192, 64, 192), 333), ((200, 200), 500), ((128, 128), 64 * 9 + 1)])
+# (512, 512) at 2 048 and 2 000 rows: C3's widths -- the decoder's last layer backward on the matrix cores (sk_last_bwd_mfma_kernel:
+# H = 512, whole 16-row blocks per workgroup) and, with a ragged workgroup split, the per-lane form beside it.
+@pytest.mark.parametrize("hidden,B", [((128,), 700), ((256, 128), 1000), ((192, 64, 192), 333), ((200, 200), 500), ((128, 128), 64 * 9 + 1),
+                                      ((512, 512), 2048), ((512, 512), 2000)])
 @pytest.mark.parametrize("dataset", ["sphere", "sigmoid"])
 def test_bf16_dense_path_tracks_oracle(hidden, B, dataset):
     D = 7 if dataset == "sigmoid" else 6

@@ -27,6 +27,9 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) void glb_void_t;
 
 __device__ __forceinline__ unsigned sk_pack(float lo, float hi) {
     const bf16x2 v = {(__bf16)lo, (__bf16)hi};
@@ -261,6 +264,136 @@ __global__ __launch_bounds__(256) void sk_last_bwd_kernel(const SkBwdArgs a) {
     }
 }
 
+// ---- last layer backward on the f32 matrix cores (d <= 8, H = 64 NT = 512: a row of h is one 1 KB piece) ------------------------------------------------------------
+// The per-lane loops above are vector-ALU-bound (216 vector instructions per KB of h: 54 us for C3's 64 MB + 64 MB).  Here a
+// workgroup walks its rows in blocks of 16 through a ring of FOUR LDS slots filled by LDS-DMA three blocks ahead (a row of h is
+// one 1 KB global_load_lds, row stride 1056 bytes; the block's dy rows are contiguous in memory: one more piece) with counted
+// waits -- a workgroup has only 8 blocks, so nothing else would hide the memory round trips -- and both products run on
+// v_mfma_f32_16x16x4_f32: exact float32 products of the bf16 h and the float32 dy, as before:
+//   dh^T[hcol][row] = W[hcol][:] . dy[row][:]      M = 16 columns of H, N = the 16 rows, K = d in two k-steps.  The M index of a
+//       PAIR of tiles is dealt so that a lane ends up with 8 consecutive columns of one row (M index 4 g + r of the pair's first
+//       tile = column 8 g + r, of its second = 8 g + 4 + r): one 16-byte LDS read of h for the relu mask, one 16-byte store.
+//   G[hcol][n] += sum_rows h[row][hcol] dy[row][n]  M = 16 columns of H, N = n (d of 16 used), K = the 16 rows in four k-steps;
+//       accumulators live across the workgroup's rows.  A from LDS: one ds_read_u16 per product.
+// Wave w owns columns 16 NT w .. of H.  Rows past the workgroup's range: dy reads as zero, nothing is stored.
+// rows_per_wg a multiple of 16 (the host checks): every piece starts on a 16-byte boundary.
+template <int NT>
+__global__ __launch_bounds__(256) void sk_last_bwd_mfma_kernel(const SkBwdArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) float sk_lds[];
+    static_assert(NT == 8, "a row of h = one LDS-DMA piece");
+    constexpr int H = 64 * NT, RS = 2 * H + 32, SLOT = 16 * RS + 1024, NSL = 4, RPW = 16 * (2 * H) / 1024 / 4;   // h pieces per wave and block
+    char* const ring = reinterpret_cast<char*>(sk_lds);                     // [NSL][16 rows of h | the block's dy: a whole 1 KB piece lands there]
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), g = lane >> 4, c = lane & 15, d = a.d;
+    const long long r0 = (long long)blockIdx.x * a.rows_per_wg, r1 = min((long long)a.rows, r0 + a.rows_per_wg);
+    const int nblk = r1 > r0 ? (int)((r1 - r0 + 15) / 16) : 0;
+    const int col0 = 16 * NT * wave;
+    // n in {0, 1, 2} blocks of this wave's pieces may stay in flight (what it stored since counts too, but a last block may store
+    // less than a whole one: the stores are left out of the allowance -- a wait for some of them is the price)
+    auto wait_vm = [&](int n) {
+        if (wave == 0) { if (n >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (RPW + 1))); else if (n == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RPW + 1)); else asm volatile("s_waitcnt vmcnt(0)"); }
+        else { if (n >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * RPW)); else if (n == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RPW)); else asm volatile("s_waitcnt vmcnt(0)"); }
+    };
+    auto issue_block = [&](int blk) {                          // rows of h: piece q of the block = row q's (H / 512) th KB ...
+        char* slot = ring + (blk & (NSL - 1)) * SLOT;
+        const long long rb = r0 + 16ll * blk;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int piece = wave * RPW + i, row = piece / (2 * H / 1024), part = piece % (2 * H / 1024);
+            const long long rr = min(rb + row, r1 - 1);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(reinterpret_cast<const char*>(a.big) + rr * (2 * H) + part * 1024 + lane * 16),
+                                             (lds_void_t*)(slot + row * RS + part * 1024), 16, 0, 0);
+        }
+        if (wave == 0) {                                       // ... and the 16 d floats of dy behind them (clamped inside the tensor)
+            const long long off = min(rb * d * 4 + lane * 16, (long long)a.rows * d * 4 - 16);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(reinterpret_cast<const char*>(a.small) + off), (lds_void_t*)(slot + 16 * RS), 16, 0, 0);
+        }
+    };
+    // A of the dh product: this wave's W rows in the paired order, k = n
+    float wa[NT][2];
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) {
+        const int hcol = col0 + 32 * (tl >> 1) + 8 * (c >> 2) + 4 * (tl & 1) + (c & 3);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int n = g + 4 * s2;
+            const float v = a.w[(long long)hcol * d + min(n, d - 1)];
+            wa[tl][s2] = n < d ? v : 0.f;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the counted waits below count LDS-DMA pieces only)
+    f32x4 G[NT];
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) G[tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float gb = 0.f;
+#pragma unroll
+    for (int q = 0; q < NSL - 1; ++q) if (q < nblk) issue_block(q);
+    for (int blk = 0; blk < nblk; ++blk) {
+        const long long rb = r0 + 16ll * blk;
+        wait_vm(min(NSL - 2, nblk - 1 - blk));                 // this wave's pieces of block blk have landed ...
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // ... everybody's; and everybody has left slot (blk - 1) & 3
+        if (blk + NSL - 1 < nblk) issue_block(blk + NSL - 1);
+        const char* hblk = ring + (blk & (NSL - 1)) * SLOT;
+        const float* dyl = reinterpret_cast<const float*>(hblk + 16 * RS);          // [16][d]
+        float dyT[2], dyB[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int n = g + 4 * s2;
+            const float v = dyl[c * d + min(n, d - 1)];
+            dyT[s2] = (rb + c < r1 && n < d) ? v : 0.f;
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float v = dyl[(4 * s4 + g) * d + min(c, d - 1)];
+            dyB[s4] = (rb + 4 * s4 + g < r1 && c < d) ? v : 0.f;
+            gb += dyB[s4];
+        }
+        // ---- G += h^T dy
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) {
+            unsigned short hv[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) hv[s4] = *reinterpret_cast<const unsigned short*>(hblk + (4 * s4 + g) * RS + 2 * (col0 + 16 * tl + c));
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+                G[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, (unsigned)hv[s4] << 16), dyB[s4], G[tl], 0, 0, 0);
+        }
+        // ---- dh = (W dy^T) * (h > 0), a pair of tiles = 8 consecutive columns of row c per lane
+#pragma unroll
+        for (int pr = 0; pr < NT / 2; ++pr) {
+            f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[2 * pr][s2], dyT[s2], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[2 * pr + 1][s2], dyT[s2], o1, 0, 0, 0);
+            }
+            const int hc = col0 + 32 * pr + 8 * g;
+            float hf[8];
+            sk_unpack8(*reinterpret_cast<const uint4*>(hblk + c * RS + 2 * hc), hf);
+            float o[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o[r] = hf[r] > 0.f ? o0[r] : 0.f; o[4 + r] = hf[4 + r] > 0.f ? o1[r] : 0.f; }
+            if (rb + c < r1) {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 pk = {sk_pack(o[0], o[1]), sk_pack(o[2], o[3]), sk_pack(o[4], o[5]), sk_pack(o[6], o[7])};
+                // (a store the compiler does not count: its own waits must not drain the LDS-DMA pieces in flight)
+                asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(a.dh + (rb + c) * H + hc), "v"(pk) : "memory");
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- the workgroup's partial image: G[hcol][n] (lane: n = c, rows 4 g + r of each tile), then the bias row
+    float* out = a.partial + (long long)blockIdx.x * ((long long)(H + 1) * d);
+    if (c < d) {
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(long long)(col0 + 16 * tl + 4 * g + r) * d + c] = G[tl][r];
+    }
+    gb += __shfl_xor(gb, 16, 64);
+    gb += __shfl_xor(gb, 32, 64);
+    if (wave == 0 && lane < d) out[(long long)H * d + lane] = gb;
+}
+
 // ---- first layer dW|db ---------------------------------------------------------------------------------------------------
 template <int DMAX>
 __global__ __launch_bounds__(256) void sk_first_bwd_kernel(const SkBwdArgs a) {
@@ -432,7 +565,15 @@ int launch_sk_last_bwd(const __bf16* h, const float* dy, const float* w, __bf16*
     SkBwdArgs a{h, dy, w, dh, partial, rows, d, H, (rows + nwg - 1) / nwg};
     const int cprw = H / 8, rpp = 256 / cprw;
     const size_t lds = (size_t)std::max(rpp - 1, 0) * cprw * (9 * d) * sizeof(float);
-    {
+    if (d <= 8 && H == 512 && a.rows_per_wg % 16 == 0 && (long long)rows * d * 4 >= 16) {
+        // the matrix-core form: rows in blocks of 16 through a ring of four LDS images of h (+ dy)
+        ProfScope ps("sk16_last_bwd", st);
+        const size_t lds_m = (size_t)4 * (16 * (2 * H + 32) + 1024);
+        static thread_local bool setm = false;
+        if (!setm) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)sk_last_bwd_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); setm = true; }
+        launch_k(ps, sk_last_bwd_mfma_kernel<8>, dim3(nwg), dim3(256), lds_m, st, a);
+        VAEK_HIP_CHECK(hipGetLastError());
+    } else {
         ProfScope ps("sk16_last_bwd", st);
         if (d <= 8) {
             static thread_local bool set8 = false;
