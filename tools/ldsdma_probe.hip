@@ -147,6 +147,38 @@ static void run(const char* buf, long long total, int G, int chunk_pieces, int s
     printf("G %3d  loading waves %d  multiplying waves %d  in flight per wave %2d  drain + barrier per chunk %d  prio %d: %.2f TB/s  (%.2f us per step)\n", G, W, C, Q, DRAIN, PRIO, W ? bytes / best * 1e-9 : 0.0, best * 1e3 / steps);
 }
 
+// the same stream through the ordinary path: global_load_dwordx4 into registers (UNR loads in flight per lane), nothing stored
+template <int W, int UNR>
+__global__ __launch_bounds__(W * 64) void stream_regs(const char* src, long long total, int chunk_pieces, int steps, unsigned* sink) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int G = gridDim.x, g = blockIdx.x;
+    unsigned acc = 0;
+    for (int s = 0; s < steps; ++s) {
+        const char* base = src + (((long long)s * G + g) * chunk_pieces * 1024ll) % total;
+        for (int k = wave; k < chunk_pieces; k += W * UNR) {
+            uint4 v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) v[u] = *reinterpret_cast<const uint4*>(base + min(k + W * u, chunk_pieces - 1) * 1024 + lane * 16);
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+        }
+    }
+    if (acc == 0x12345678u) sink[g] = acc;
+}
+template <int W, int UNR>
+static void run_regs(const char* buf, long long total, int G, int chunk_pieces, int steps, unsigned* sink, const char* what) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((stream_regs<W, UNR>), dim3(G), dim3(W * 64), 0, 0, buf, total, chunk_pieces, steps, sink);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    printf("%s, registers: %d waves x %d loads in flight: %.2f TB/s\n", what, W, UNR, (double)G * chunk_pieces * 1024.0 * steps / best * 1e-9);
+}
+
 int main(int argc, char** argv) {
     const long long total = 4ll << 30;
     char* buf; unsigned* sink;
@@ -166,6 +198,18 @@ int main(int argc, char** argv) {
     run<2, 4, 26, 1, 0>(buf, total, G, 50, steps, sink);
     run<2, 4, 26, 0, 0>(buf, total, G, 50, steps, sink);
     run<1, 4, 50, 0, 0>(buf, total, G, 50, steps, sink);
+    // the same chunk again and again: every step after the first is served by the XCD's L2
+    const long long resident = (long long)G * 50 * 1024;
+    printf("L2-resident source (%lld MB re-read every step):\n", resident >> 20);
+    run<4, 0, 13, 0, 0>(buf, resident, G, 50, steps, sink);
+    run<8, 0, 13, 0, 0>(buf, resident, G, 50, steps, sink);
+    run<4, 4, 13, 0, 0>(buf, resident, G, 50, steps, sink);
+    run_regs<4, 4>(buf, resident, G, 50, steps, sink, "L2-resident");
+    run_regs<8, 4>(buf, resident, G, 50, steps, sink, "L2-resident");
+    run_regs<8, 7>(buf, resident, G, 50, steps, sink, "L2-resident");
+    run_regs<4, 4>(buf, total, G, 50, steps, sink, "HBM");
+    run_regs<8, 4>(buf, total, G, 50, steps, sink, "HBM");
+    run_regs<8, 7>(buf, total, G, 50, steps, sink, "HBM");
     run_ring<0, 1>(buf, total, G, steps, sink);
     run_ring<1, 1>(buf, total, G, steps, sink);
     run_ring<0, 3>(buf, total, G, steps, sink);
