@@ -277,7 +277,9 @@ __global__ __launch_bounds__(256) void sk_last_bwd_kernel(const SkBwdArgs a) {
 //       accumulators live across the workgroup's rows.  A from LDS: one ds_read_u16 per product.
 // Wave w owns columns 16 NT w .. of H.  Rows past the workgroup's range: dy reads as zero, nothing is stored.
 // rows_per_wg a multiple of 16 (the host checks): every piece starts on a 16-byte boundary.
-template <int NT>
+// FIRST: the first layer's [x | 1]^T dY instead -- the same G product with big = dY, small = x and a ones column behind x's d
+// (its row of the image is the bias gradient); no dh.
+template <int NT, bool FIRST = false>
 __global__ __launch_bounds__(256) void sk_last_bwd_mfma_kernel(const SkBwdArgs a) {
     extern __shared__ __attribute__((aligned(1024))) float sk_lds[];
     static_assert(NT == 8, "a row of h = one LDS-DMA piece");
@@ -309,15 +311,17 @@ __global__ __launch_bounds__(256) void sk_last_bwd_mfma_kernel(const SkBwdArgs a
         }
     };
     // A of the dh product: this wave's W rows in the paired order, k = n
-    float wa[NT][2];
+    [[maybe_unused]] float wa[NT][2];
+    if constexpr (!FIRST) {
 #pragma unroll
-    for (int tl = 0; tl < NT; ++tl) {
-        const int hcol = col0 + 32 * (tl >> 1) + 8 * (c >> 2) + 4 * (tl & 1) + (c & 3);
+        for (int tl = 0; tl < NT; ++tl) {
+            const int hcol = col0 + 32 * (tl >> 1) + 8 * (c >> 2) + 4 * (tl & 1) + (c & 3);
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int n = g + 4 * s2;
-            const float v = a.w[(long long)hcol * d + min(n, d - 1)];
-            wa[tl][s2] = n < d ? v : 0.f;
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int n = g + 4 * s2;
+                const float v = a.w[(long long)hcol * d + min(n, d - 1)];
+                wa[tl][s2] = n < d ? v : 0.f;
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the counted waits below count LDS-DMA pieces only)
@@ -334,18 +338,21 @@ __global__ __launch_bounds__(256) void sk_last_bwd_mfma_kernel(const SkBwdArgs a
         if (blk + NSL - 1 < nblk) issue_block(blk + NSL - 1);
         const char* hblk = ring + (blk & (NSL - 1)) * SLOT;
         const float* dyl = reinterpret_cast<const float*>(hblk + 16 * RS);          // [16][d]
-        float dyT[2], dyB[4];
+        [[maybe_unused]] float dyT[2];
+        float dyB[4];
+        if constexpr (!FIRST) {
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int n = g + 4 * s2;
-            const float v = dyl[c * d + min(n, d - 1)];
-            dyT[s2] = (rb + c < r1 && n < d) ? v : 0.f;
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int n = g + 4 * s2;
+                const float v = dyl[c * d + min(n, d - 1)];
+                dyT[s2] = (rb + c < r1 && n < d) ? v : 0.f;
+            }
         }
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             const float v = dyl[(4 * s4 + g) * d + min(c, d - 1)];
-            dyB[s4] = (rb + 4 * s4 + g < r1 && c < d) ? v : 0.f;
-            gb += dyB[s4];
+            dyB[s4] = rb + 4 * s4 + g < r1 ? (c < d ? v : (FIRST && c == d) ? 1.f : 0.f) : 0.f;
+            if constexpr (!FIRST) gb += dyB[s4];
         }
         // ---- G += h^T dy
 #pragma unroll
@@ -358,6 +365,7 @@ __global__ __launch_bounds__(256) void sk_last_bwd_mfma_kernel(const SkBwdArgs a
                 G[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, (unsigned)hv[s4] << 16), dyB[s4], G[tl], 0, 0, 0);
         }
         // ---- dh = (W dy^T) * (h > 0), a pair of tiles = 8 consecutive columns of row c per lane
+        if constexpr (!FIRST)
 #pragma unroll
         for (int pr = 0; pr < NT / 2; ++pr) {
             f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
@@ -382,6 +390,15 @@ __global__ __launch_bounds__(256) void sk_last_bwd_mfma_kernel(const SkBwdArgs a
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- the workgroup's partial image: G[hcol][n] (lane: n = c, rows 4 g + r of each tile), then the bias row
+    if constexpr (FIRST) {                                     // [(d + 1)][H]: row n = c, four consecutive columns per tile and lane
+        float* out = a.partial + (long long)blockIdx.x * ((long long)(d + 1) * H);
+        if (c <= d) {
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl)
+                *reinterpret_cast<float4*>(out + (long long)c * H + col0 + 16 * tl + 4 * g) = make_float4(G[tl][0], G[tl][1], G[tl][2], G[tl][3]);
+        }
+        return;
+    }
     float* out = a.partial + (long long)blockIdx.x * ((long long)(H + 1) * d);
     if (c < d) {
 #pragma unroll
@@ -595,7 +612,15 @@ int launch_sk_first_bwd(const float* x, const __bf16* dy, float* partial, float*
     SkBwdArgs a{dy, x, nullptr, nullptr, partial, rows, d, H, (rows + nwg - 1) / nwg};
     const int cprw = H / 8, rpp = 256 / cprw;
     const size_t lds = (size_t)std::max(rpp - 1, 0) * cprw * ((d + 1) * 8) * sizeof(float);
-    {
+    if (d <= 8 && H == 512 && a.rows_per_wg % 16 == 0 && (long long)rows * d * 4 >= 16) {
+        // the matrix-core form (sk_last_bwd_mfma_kernel's G product with a ones column)
+        ProfScope ps("sk16_first_bwd", st);
+        const size_t lds_m = (size_t)4 * (16 * (2 * H + 32) + 1024);
+        static thread_local bool setm = false;
+        if (!setm) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)sk_last_bwd_mfma_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); setm = true; }
+        launch_k(ps, sk_last_bwd_mfma_kernel<8, true>, dim3(nwg), dim3(256), lds_m, st, a);
+        VAEK_HIP_CHECK(hipGetLastError());
+    } else {
         ProfScope ps("sk16_first_bwd", st);
         if (d <= 8) {
             static thread_local bool set8 = false;
