@@ -143,6 +143,11 @@ __global__ __launch_bounds__(64 * WM * WN) void hs_nt_kernel(const HsArgs g) {
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
     const int nt = g.K / BK;
+    // dX with a ring of two: the relu-mask source (this wave's output tile of the layer's bf16 input, 16 x 16 bytes per lane) is
+    // fetched UNDER the k-loop -- issued behind the second stage, complete at the next tile's wait, which is vmcnt(0) in a ring of
+    // two anyway -- instead of in front of the epilogue, where its 64 MB per launch were 16 of the kernel's 59 us
+    constexpr bool PRE_MASK = EPI == HS_DX && NS == 2;
+    [[maybe_unused]] uint4 pmask[PRE_MASK ? TM : 1][PRE_MASK ? TN : 1][2];
 #ifdef VAEK_HS_STAMPS
     unsigned long long st_wait = 0, st_bar = 0, st_issue = 0, st_comp = 0;
 #endif
@@ -158,6 +163,24 @@ __global__ __launch_bounds__(64 * WM * WN) void hs_nt_kernel(const HsArgs g) {
         __builtin_amdgcn_s_barrier();                      // ... and everyone's; everyone is done reading tile kt - 1
         HS_STAMP(s2);
         if (kt + NS - 1 < nt) stage(kt + NS - 1, fill);    // into the slot tile kt - 1 was read from
+        if constexpr (PRE_MASK) {
+            // (fragment (i, j) behind the stage of k-tile i TN + j: spread over the loop, each wait absorbs an eighth of the bytes)
+            const int nb_ = n0 + wn * (BN / WN);
+            if (g.aux && nb_ < g.N) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if (kt == min(i * TN + j, nt - 1)) {
+                            const int m = m0 + wm * (BM / WM) + i * 32 + (lane & 31);
+                            const long long ro = (long long)(m < g.M ? m : g.M - 1) * g.ldc;
+#pragma unroll
+                            for (int u = 0; u < 2; ++u)
+                                pmask[i][j][u] = *reinterpret_cast<const uint4*>(g.aux + ro + nb_ + j * 32 + 16 * u + 8 * (lane >> 5));
+                        }
+                    }
+            }
+        }
         HS_STAMP(s3);
         HS_ADD(st_wait, s0, s1); HS_ADD(st_bar, s1, s2); HS_ADD(st_issue, s2, s3);
         const char* base = smem + slot * BUF;
@@ -210,7 +233,10 @@ __global__ __launch_bounds__(64 * WM * WN) void hs_nt_kernel(const HsArgs g) {
             uint4 mask[2];
             if (EPI == HS_DX && g.aux) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) mask[u] = *reinterpret_cast<const uint4*>(g.aux + rowoff + nj + 16 * u + 8 * h);
+                for (int u = 0; u < 2; ++u) {
+                    if constexpr (PRE_MASK) mask[u] = pmask[i][j][u];
+                    else mask[u] = *reinterpret_cast<const uint4*>(g.aux + rowoff + nj + 16 * u + 8 * h);
+                }
             }
             unsigned d[4][2];
 #pragma unroll
