@@ -34,9 +34,15 @@ using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
-// 16 bytes per lane global -> LDS; the LDS side is wave-uniform base + 16 * lane
+// 16 bytes per lane global -> LDS; the LDS side is wave-uniform base + 16 * lane.  In inline assembly since round 3: through
+// __builtin_amdgcn_global_load_lds hipcc knows that LDS is being written and puts s_waitcnt vmcnt(0) in front of the next LDS
+// read it cannot tell apart -- in every kernel of this file that was the operand reads of the k-tile being multiplied, RIGHT BEHIND
+// the issue of the next k-tile's loads: the ring never overlapped a load with a product (ISA: "8 x global_load_lds, s_waitcnt
+// vmcnt(0), ds_read_b128 ..."; round 2's ablation found loads and MFMAs additive and every ring depth equally fast).  Every wait
+// on these loads is the kernels' own counted one (wait_tiles) in front of a barrier.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((glb_void_t*)gsrc, (lds_void_t*)lds_wave_base, 16, 0, 0);
+    const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds_void_t*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v) : "memory");
 }
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     const bf16x2 v = {(__bf16)lo, (__bf16)hi};
@@ -933,10 +939,11 @@ int launch_hs_dw(const __bf16* x, const __bf16* dy, float* slab0, int64_t slab_s
     HsDwArgs g{};
     g.X = x; g.dY = dy; g.slab = slab0; g.rows = rows; g.M = n_in; g.N = n_out; g.ldx = n_in; g.ldy = n_out;
     g.rows_per_split = rows_per_split; g.slab_stride = slab_stride;
-    // -1 = by shape: 256 x 128 tiles (a quarter fewer operand bytes through L2 -> LDS per product: C3's 512 x 512 layers 75 -> 63 us)
+    // -1 = by shape: 256 x 128 tiles (a quarter fewer operand bytes through L2 -> LDS per product: C3's 512 x 512 layers 75 -> 63 us,
+    // 45 us with the LDS-DMA in inline assembly and a ring of three)
     // where they still give most CUs a workgroup, 128 x 128 otherwise; every variant bitwise identical for the same splits
     const bool big = n_in % 256 == 0 && (long long)(n_in / 256) * ((n_out + 127) / 128) * S >= 192;
-    const int vi = g_hs_variant_tn >= 0 ? g_hs_variant_tn : (big ? 5 : 0);
+    const int vi = g_hs_variant_tn >= 0 ? g_hs_variant_tn : (big ? 7 : 0);      // (7: ring of three 64-row k-tiles -- 45 us where the ring of two takes 52, now that loads and products overlap)
     if (vi < 0 || vi >= kTnCount) { set_error("unknown bf16-storage dW variant %d", vi); return VAEK_ERR_INVALID; }
     const HsTnVariant& v = kTn[vi];
     g.tiles_m = (n_in + v.bm - 1) / v.bm; g.tiles_n = (n_out + 127) / 128;

@@ -279,6 +279,13 @@ __global__ __launch_bounds__(256) void sk_last_bwd_kernel(const SkBwdArgs a) {
 // rows_per_wg a multiple of 16 (the host checks): every piece starts on a 16-byte boundary.
 // FIRST: the first layer's [x | 1]^T dY instead -- the same G product with big = dY, small = x and a ones column behind x's d
 // (its row of the image is the bias gradient); no dh.
+// One 1 KB LDS-DMA piece in inline assembly: through the builtin hipcc knows that LDS is being written and puts s_waitcnt vmcnt(0)
+// in front of every later LDS read it cannot tell apart -- the ring below was drained four times per block (ISA; 36 us per launch).
+// The waits are this kernel's own (counted) ones.
+__device__ __forceinline__ void sk_glds16(const void* gsrc, void* lds_wave_base) {
+    const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds_void_t*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v) : "memory");
+}
 template <int NT, bool FIRST = false>
 __global__ __launch_bounds__(256) void sk_last_bwd_mfma_kernel(const SkBwdArgs a) {
     extern __shared__ __attribute__((aligned(1024))) float sk_lds[];
@@ -302,12 +309,11 @@ __global__ __launch_bounds__(256) void sk_last_bwd_mfma_kernel(const SkBwdArgs a
         for (int i = 0; i < RPW; ++i) {
             const int piece = wave * RPW + i, row = piece / (2 * H / 1024), part = piece % (2 * H / 1024);
             const long long rr = min(rb + row, r1 - 1);
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(reinterpret_cast<const char*>(a.big) + rr * (2 * H) + part * 1024 + lane * 16),
-                                             (lds_void_t*)(slot + row * RS + part * 1024), 16, 0, 0);
+            sk_glds16(reinterpret_cast<const char*>(a.big) + rr * (2 * H) + part * 1024 + lane * 16, slot + row * RS + part * 1024);
         }
         if (wave == 0) {                                       // ... and the 16 d floats of dy behind them (clamped inside the tensor)
             const long long off = min(rb * d * 4 + lane * 16, (long long)a.rows * d * 4 - 16);
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(reinterpret_cast<const char*>(a.small) + off), (lds_void_t*)(slot + 16 * RS), 16, 0, 0);
+            sk_glds16(reinterpret_cast<const char*>(a.small) + off, slot + 16 * RS);
         }
     };
     // A of the dh product: this wave's W rows in the paired order, k = n
@@ -340,19 +346,22 @@ __global__ __launch_bounds__(256) void sk_last_bwd_mfma_kernel(const SkBwdArgs a
         const float* dyl = reinterpret_cast<const float*>(hblk + 16 * RS);          // [16][d]
         [[maybe_unused]] float dyT[2];
         float dyB[4];
-        if constexpr (!FIRST) {
+        {
+            float rawT[2] = {0.f, 0.f}, rawB[4];               // all six LDS reads first, the selects behind them
+            if constexpr (!FIRST) {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int n = g + 4 * s2;
-                const float v = dyl[c * d + min(n, d - 1)];
-                dyT[s2] = (rb + c < r1 && n < d) ? v : 0.f;
+                for (int s2 = 0; s2 < 2; ++s2) rawT[s2] = dyl[c * d + min(g + 4 * s2, d - 1)];
             }
-        }
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const float v = dyl[(4 * s4 + g) * d + min(c, d - 1)];
-            dyB[s4] = rb + 4 * s4 + g < r1 ? (c < d ? v : (FIRST && c == d) ? 1.f : 0.f) : 0.f;
-            if constexpr (!FIRST) gb += dyB[s4];
+            for (int s4 = 0; s4 < 4; ++s4) rawB[s4] = dyl[(4 * s4 + g) * d + min(c, d - 1)];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) dyT[s2] = (rb + c < r1 && g + 4 * s2 < d) ? rawT[s2] : 0.f;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                dyB[s4] = rb + 4 * s4 + g < r1 ? (c < d ? rawB[s4] : (FIRST && c == d) ? 1.f : 0.f) : 0.f;
+                if constexpr (!FIRST) gb += dyB[s4];
+            }
         }
         // ---- G += h^T dy
 #pragma unroll
