@@ -281,7 +281,12 @@ int vaek_train_steps_gen(vaek_ctx* ctx, float* params, float* grads, float* m, f
  * bf16 copies (all optional, NULL = none; 16-byte aligned): `x_bf16` / `dy_bf16` / `y_bf16` INPUTS are bf16 images of the float32
  * tensor of the same name that the caller vouches for (an earlier call's output copy, or vaek_to_bf16) -- the LDS-DMA form then
  * skips its own conversion pass, the other forms ignore them; `y_bf16` / `out_bf16` OUTPUTS are written with the bf16 rounding of
- * the float32 result in every form (from the epilogue where the form can, by a conversion pass otherwise). */
+ * the float32 result in every form (from the epilogue where the form can, by a conversion pass otherwise).
+ * LEAN forms (round 3: a hidden tensor of the conv VAE lives in HBM as bf16 only; LDS-DMA shapes only, VAEK_ERR_INVALID elsewhere):
+ *   - the float32 INPUT (x, y of the transposed call; x / dy of the kernel gradient) may be NULL when its bf16 copy is given;
+ *   - the float32 RESULT (y, out) may be NULL when its bf16 copy is asked for -- also on the one-channel forward layer's matrix-core form;
+ *   - relu bit 1 (relu = 2 or 3): `mask` points to the bf16 copy of the mask source instead of the float32 tensor
+ *     ([mask > 0] is the same set either way: bf16 rounding keeps the sign and never reaches zero from a normal number). */
 int vaek_conv2d_forward_workspace(int32_t batch, int32_t height, int32_t width, int32_t c_in, int32_t c_out, int32_t transposed, size_t* bytes);
 int vaek_conv2d_forward(const float* x, const float* w, const float* bias, const float* mask, float* y, int32_t batch, int32_t height,
                         int32_t width, int32_t c_in, int32_t c_out, int32_t relu, void* workspace, const void* x_bf16, void* y_bf16,
@@ -301,8 +306,10 @@ int vaek_conv2d_transpose_forward(const float* y, const float* w, const float* b
 int vaek_conv2d_weight_grad_workspace(int32_t batch, int32_t height, int32_t width, int32_t c_in, int32_t c_out, size_t* bytes);
 int vaek_conv2d_weight_grad(const float* x, const float* dy, float* dw, float* dbias, void* workspace, int32_t batch, int32_t height,
                             int32_t width, int32_t c_in, int32_t c_out, const void* x_bf16, const void* dy_bf16, void* stream);
-/* dbias[c] = sum over the pixels of dy[pixels][c] (the bias gradient of a transposed layer); workspace: 512 * c floats. */
+/* dbias[c] = sum over the pixels of dy[pixels][c] (the bias gradient of a transposed layer); workspace: 512 * c floats.
+ * _bf16: the same sums (float32 accumulation, fixed order) of a bf16 tensor -- c a power of two in 8 .. 2048, 16-byte aligned. */
 int vaek_conv2d_bias_grad(const float* dy, float* dbias, void* workspace, int64_t pixels, int32_t c, void* stream);
+int vaek_conv2d_bias_grad_bf16(const void* dy_bf16, float* dbias, void* workspace, int64_t pixels, int32_t c, void* stream);
 /* Dense + reparameterisation (networks.py:72-74) as one block: mu = x @ w + b, samples = mu + exp(logvar_e / 2) * z1. */
 int vaek_dense_fwd_reparam(vaek_ctx* ctx, const float* x, const float* w, const float* b, float* mu, float* samples, const float* z1,
                            const float* logvar_e, int32_t rows, int32_t n_in, int32_t n_out, void* stream);

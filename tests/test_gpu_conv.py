@@ -348,7 +348,7 @@ def test_conv_vae_loss_and_every_gradient_leaf(size, widths, L, B, tdv, monkeypa
     p, x, z1, z2 = _conv_problem(cfg, B)
     loss, g = CO.loss_and_grad(cfg, p, x, z1, z2)
     eloss, eg = _bf16_emulation_grads(cfg, p, x, z1, z2)
-    net = ConvVAE(B, size, widths, L, -1.5, tdv)
+    net = ConvVAE(B, size, widths, L, -1.5, tdv, lean=False)      # (the per-call emulation below reads the float32 twins of the hidden tensors)
     assert [n for n, _ in net.leaf_shapes()] == [n for n, _ in cfg.leaves()] and net.n_params == cfg.n_params()
     params, grads = net.new_flat(), net.new_flat()
     for name in net.leaves:
@@ -457,3 +457,32 @@ def test_conv_vae_at_the_benched_size_is_repeatable_and_shard_additive():
         a, b = acc[off:off + k], g1[off:off + k].double()
         worst[name] = float((a - b).abs().max() / (b.abs().max() + 1e-30))
     assert max(worst.values()) <= 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+
+
+def test_lean_conv_vae_is_the_float32_twin_model_bit_for_bit():
+    """ConvVAE(lean=True) keeps the hidden activations and their gradients as bf16 ONLY (no float32 twin written, relu masks from the
+    bf16 copies: vaek_conv2d_forward's lean forms).  Every product reads the same bf16 operands as with lean=False, so the loss and
+    every gradient leaf must be BITWISE equal -- except the transposed layers' bias gradients, which become column sums of the bf16
+    gradient instead of the float32 one (2^-9 rounding per term, random sign: 2e-3 of the leaf's max-abs)."""
+    from vae_training_amd.conv_vae import ConvVAE
+    B, S, widths, L = 64, 64, (32, 64, 128, 256), 32
+    a, b = ConvVAE(B, S, widths, L, -3.0, True, lean=True), ConvVAE(B, S, widths, L, -3.0, True, lean=False)
+    assert a.lean and not b.lean
+    g = torch.Generator(device="cpu").manual_seed(5)
+    params = a.new_flat()
+    params.copy_((torch.randn(a.P, generator=g) * 0.05).cuda())
+    for name, (off, shape) in a.leaves.items():                      # (padding floats stay zero)
+        pass
+    x = torch.rand(B, S, S, 1, generator=g).cuda(); z1 = torch.randn(B, L, generator=g).cuda(); z2 = torch.randn(B, S, S, 1, generator=g).cuda()
+    ga, gb = a.new_flat(), b.new_flat()
+    oa = a.loss_and_grad(params, ga, x, z1, z2).clone(); ob = b.loss_and_grad(params, gb, x, z1, z2).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(oa[:3], ob[:3]), (oa, ob)
+    for name in a.leaves:
+        va, vb = a.view(ga, name), b.view(gb, name)
+        if name.startswith("Decoder/ConvT") and name.endswith("/bias") and not name.startswith("Decoder/ConvT3"):
+            assert float((va - vb).abs().max()) <= 2e-3 * float(vb.abs().max()) + 1e-30, name
+        else:
+            assert torch.equal(va, vb), name
+    # a lean model with widths the LDS-DMA kernels do not cover falls back to the float32 twins by itself
+    assert not ConvVAE(8, 16, (4, 8, 8, 16), 5, -1.5, True).lean

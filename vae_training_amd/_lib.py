@@ -81,6 +81,7 @@ SIGNATURES = {
     "vaek_to_bf16": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "vaek_conv2d_forward_workspace": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_size_t)]),
     "vaek_conv2d_bias_grad": (C.c_int, [_vp, _vp, _vp, C.c_int64, _i32, _vp]),
+    "vaek_conv2d_bias_grad_bf16": (C.c_int, [_vp, _vp, _vp, C.c_int64, _i32, _vp]),
     "vaek_dense_fwd_reparam": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vaek_reparam_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_int64, _vp, _vp]),
     "vaek_conv2d_transpose_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),

@@ -31,10 +31,18 @@ def _pair(r):
 
 
 class ConvVAE:
-    def __init__(self, batch, size=64, widths=(32, 64, 128, 256), latent_dim=32, epsilon=-3.0, tunable_decoder_var=True, device=0, world=1):
+    def __init__(self, batch, size=64, widths=(32, 64, 128, 256), latent_dim=32, epsilon=-3.0, tunable_decoder_var=True, device=0, world=1,
+                 lean=True):
         """batch: THIS rank's rows; world > 1: data parallel -- every mean is taken over batch * world rows, so the SUM of the ranks' flat
-        gradients (train_step's `all_reduce`) is the global batch's gradient and every replica applies the same Adam update."""
+        gradients (train_step's `all_reduce`) is the global batch's gradient and every replica applies the same Adam update.
+        lean (round 3): the hidden activations and their gradients live in HBM as bf16 ONLY -- no float32 twin is written, relu masks
+        come from the bf16 copies, the transposed layers' bias gradients are column sums of the bf16 gradient.  Every product reads
+        the same bf16 operands either way, so all leaves but those bias gradients are bitwise the same as with lean=False
+        (tests/test_gpu_conv.py).  Needs the LDS-DMA kernels' shapes (power-of-two widths in 32 .. 256, power-of-two image): other
+        models run as before."""
         assert size % 16 == 0 and len(widths) == 4
+        self.lean = bool(lean) and all(32 <= w <= 256 and (w & (w - 1)) == 0 for w in widths) and (size & (size - 1)) == 0 and \
+            batch * (size // 16) ** 2 >= 64
         self.world = int(world)
         self.B, self.S, self.widths, self.L, self.eps_cli, self.tdv = batch, size, tuple(widths), latent_dim, float(epsilon), tunable_decoder_var
         self.bott = (size // 16) ** 2 * widths[3]
@@ -80,10 +88,13 @@ class ConvVAE:
         B, S, L, e = x.shape[0], self.S, self.L, self.eng
         P = lambda n: self.view(params, n)
         G = lambda n: self.view(grads, n)
-        # ---- forward (every tensor a bf16-operand kernel will read again gets its bf16 copy from the epilogue that produces it)
+        # ---- forward (every tensor a bf16-operand kernel will read again gets its bf16 copy from the epilogue that produces it; lean:
+        # the hidden ones get NOTHING else -- acts[1..3], dec[1..2] and the gradients below are None beside their bf16 copies)
+        lean = self.lean
         acts, acts16 = [x], [None]
         for i in range(4):
-            y, y16 = _pair(conv2d_forward(acts[-1], P(f"Encoder/Conv{i}/kernel"), P(f"Encoder/Conv{i}/bias"), relu=True, x16=acts16[-1], want16=i < 3))
+            y, y16 = _pair(conv2d_forward(acts[-1], P(f"Encoder/Conv{i}/kernel"), P(f"Encoder/Conv{i}/bias"), relu=True, x16=acts16[-1], want16=i < 3,
+                                          want32=not (lean and i < 3)))
             acts.append(y); acts16.append(y16)
         flat = acts[-1].view(B, self.bott)
         lv = P("epsilon_p")
@@ -92,7 +103,7 @@ class ConvVAE:
         dec16 = [to_bf16(dec[0])]
         for i in range(4):
             y, y16 = _pair(conv2d_transpose_forward(dec[-1], P(f"Decoder/ConvT{i}/kernel"), P(f"Decoder/ConvT{i}/bias"), relu=i < 3,
-                                                    y16=dec16[-1], want16=i < 2))
+                                                    y16=dec16[-1], want16=i < 2, want32=not (lean and i < 2)))
             dec.append(y); dec16.append(y16)
         bt = B * self.world                                                                       # the means' denominator: the GLOBAL batch
         out4, d, _ = e.elbo_fwd_bwd(x.view(B, S * S), dec[4].view(B, S * S), None, z2.view(B, S * S), mu, lv, self.eps_cli, batch_total=bt,
@@ -100,10 +111,12 @@ class ConvVAE:
         # ---- backward: decoder
         d, d16 = d.view(B, S, S, 1), None
         for i in reversed(range(4)):
-            inp = dec[i]
-            conv2d_weight_grad(d, inp, want_bias=False, dw=G(f"Decoder/ConvT{i}/kernel"), x16=d16, dy16=dec16[i])
-            conv2d_bias_grad(d, G(f"Decoder/ConvT{i}/bias"))
-            d, d16 = _pair(conv2d_forward(d, P(f"Decoder/ConvT{i}/kernel"), None, relu=False, mask=inp, x16=d16, want16=i > 0))   # adjoint of the adjoint + relu below
+            inp, inp16 = dec[i], dec16[i]
+            conv2d_weight_grad(d, inp, want_bias=False, dw=G(f"Decoder/ConvT{i}/kernel"), x16=d16, dy16=inp16)
+            conv2d_bias_grad(d if d is not None else d16, G(f"Decoder/ConvT{i}/bias"))
+            m16 = inp16 if lean and inp16 is not None else None                                   # the relu mask from the bf16 copy where there is one
+            d, d16 = _pair(conv2d_forward(d, P(f"Decoder/ConvT{i}/kernel"), None, relu=False, mask=None if m16 is not None else inp, mask16=m16, x16=d16,
+                                          want16=i > 0, want32=not (lean and i > 0)))             # adjoint of the adjoint + relu below
         d = d.view(B, self.bott)
         dwb = e.dense_bwd_dw(samples, d)                                                          # [kernel | bias] rows
         G("Decoder/FC/kernel").copy_(dwb[:L]); G("Decoder/FC/bias").copy_(dwb[L])
@@ -115,10 +128,12 @@ class ConvVAE:
         d16 = to_bf16(d)
         # ---- backward: encoder
         for i in reversed(range(4)):
-            inp = acts[i]
-            conv2d_weight_grad(inp, d, dw=G(f"Encoder/Conv{i}/kernel"), db=G(f"Encoder/Conv{i}/bias"), x16=acts16[i], dy16=d16)
+            inp, inp16 = acts[i], acts16[i]
+            conv2d_weight_grad(inp, d, dw=G(f"Encoder/Conv{i}/kernel"), db=G(f"Encoder/Conv{i}/bias"), x16=inp16, dy16=d16)
             if i > 0:
-                d, d16 = _pair(conv2d_transpose_forward(d, P(f"Encoder/Conv{i}/kernel"), None, relu=False, mask=inp, y16=d16, want16=i > 1))
+                m16 = inp16 if lean else None
+                d, d16 = _pair(conv2d_transpose_forward(d, P(f"Encoder/Conv{i}/kernel"), None, relu=False, mask=None if m16 is not None else inp, mask16=m16,
+                                                        y16=d16, want16=i > 1, want32=not (lean and i > 1)))
         if self.tdv:
             G("epsilon").copy_(out4[3:4] * self.eps_cli)                                          # eps = param * eps_cli
         return out4

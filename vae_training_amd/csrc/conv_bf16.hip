@@ -443,6 +443,46 @@ __global__ __launch_bounds__(256) void conv_colsum4_kernel(const float4* dy4, fl
     }
 }
 
+// column sums of a bf16 tensor as a flat 16-byte stream (C a power of two >= 8, <= 2048; pixels * C a multiple of 8): thread t of a
+// block always sees the same 8 columns (8 t mod C); two independent accumulator sets, then the block's threads of one column
+// octet meet through LDS.  float32 sums of the bf16 values, fixed order.
+__global__ __launch_bounds__(256) void conv_colsum8_bf16_kernel(const uint4* dy8, float* partial, long long n8, int C, long long chunk) {
+    __shared__ float sh[256][9];
+    const long long f0 = blockIdx.x * chunk, f1 = min(n8, f0 + chunk);
+    float a[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[u][e] = 0.f;
+    auto add8 = [&](float (&acc)[8], const uint4 v) {
+        acc[0] += __builtin_bit_cast(float, v.x << 16); acc[1] += __builtin_bit_cast(float, v.x & 0xffff0000u);
+        acc[2] += __builtin_bit_cast(float, v.y << 16); acc[3] += __builtin_bit_cast(float, v.y & 0xffff0000u);
+        acc[4] += __builtin_bit_cast(float, v.z << 16); acc[5] += __builtin_bit_cast(float, v.z & 0xffff0000u);
+        acc[6] += __builtin_bit_cast(float, v.w << 16); acc[7] += __builtin_bit_cast(float, v.w & 0xffff0000u);
+    };
+    long long f = f0 + threadIdx.x;
+    for (; f + 768 < f1; f += 1024) {
+        const uint4 v0 = dy8[f], v1 = dy8[f + 256], v2 = dy8[f + 512], v3 = dy8[f + 768];
+        add8(a[0], v0); add8(a[1], v1); add8(a[0], v2); add8(a[1], v3);
+    }
+    for (; f < f1; f += 256) add8(a[0], dy8[f]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sh[threadIdx.x][e] = a[0][e] + a[1][e];
+    __syncthreads();
+    const int Q = C / 8;                                 // column octets; Q divides 256
+    if ((int)threadIdx.x < Q) {
+        float t8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t8[e] = 0.f;
+        for (int g2 = threadIdx.x; g2 < 256; g2 += Q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t8[e] += sh[g2][e];
+        float* o = partial + (long long)blockIdx.x * C + 8 * threadIdx.x;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = t8[e];
+    }
+}
+
 static int conv_wgrad_splits(long long pixels, int M, int N) {
     const long long tiles = (long long)((M + CBM - 1) / CBM) * ((N + CBN - 1) / CBN);
     long long S = std::max(1ll, 1024 / tiles);
@@ -857,7 +897,7 @@ __global__ __launch_bounds__(256) void thin_conv_fwd_mfma_kernel(const ThinArgs 
             if (g.mask) v = mk[r] > 0.f ? v : 0.f;
             const float nb = __shfl_down(v, 1, 64);        // the odd neighbour's channel: even lanes store bf16 pairs
             if (q < g.pixels) {
-                g.y[q * g.C + c0 + i] = v;
+                if (g.y) g.y[q * g.C + c0 + i] = v;
                 if (g.y16 && !(i & 1)) {
                     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
                     const bf16x2_t pr = {(__bf16)v, (__bf16)nb};
@@ -931,8 +971,8 @@ extern "C" int vaek_conv2d_forward_workspace(int32_t batch, int32_t height, int3
     *bytes = f.ok ? f.bytes : 0;
     return VAEK_OK;
 }
-static int conv_forward_fast(int mode, const ConvFFast& f, const float* x, const float* w, const float* bias, const float* mask, float* out,
-                             void* workspace, const void* x16, void* out16, int batch, int H, int W, int Cin, int Cout, bool relu, hipStream_t st) {
+static int conv_forward_fast(int mode, const ConvFFast& f, const float* x, const float* w, const float* bias, const float* mask, const void* mask16,
+                             float* out, void* workspace, const void* x16, void* out16, int batch, int H, int W, int Cin, int Cout, bool relu, hipStream_t st) {
     char* ws = static_cast<char*>(workspace);
     const __bf16* zeros = conv_zero_page();
     if (!zeros) { set_error("convolution: no page of zeros (hipGetSymbolAddress)"); return VAEK_ERR_HIP; }
@@ -945,7 +985,7 @@ static int conv_forward_fast(int mode, const ConvFFast& f, const float* x, const
         xb = mine;
     }
     if (rc == VAEK_OK) rc = mode == 0 ? launch_cvt_bf16_t(w, wb, 16 * Cin, Cout, nullptr, st) : launch_cvt_bf16(w, wb, (int64_t)16 * Cin * Cout, nullptr, st);
-    if (rc == VAEK_OK) rc = launch_hs_conv(mode, xb, wb, zeros, bias, mask, out, static_cast<__bf16*>(out16), batch, H, W, Cin, Cout, relu, st);
+    if (rc == VAEK_OK) rc = launch_hs_conv(mode, xb, wb, zeros, bias, mask, static_cast<const __bf16*>(mask16), out, static_cast<__bf16*>(out16), batch, H, W, Cin, Cout, relu, st);
     return rc;
 }
 
@@ -962,9 +1002,14 @@ extern "C" int vaek_conv2d_weight_grad_workspace(int32_t batch, int32_t height, 
 extern "C" int vaek_conv2d_weight_grad(const float* x, const float* dy, float* dw, float* dbias, void* workspace, int32_t batch,
                                        int32_t height, int32_t width, int32_t c_in, int32_t c_out, const void* x_bf16, const void* dy_bf16,
                                        void* stream) {
-    if (!x || !dy || !dw || !workspace || batch < 1 || height < 2 || width < 2 || (height & 1) || (width & 1) || c_in < 1 || c_out < 1 ||
-        !aligned16(x_bf16) || !aligned16(dy_bf16)) {
+    // (x / dy may be null beside their bf16 copies where the LDS-DMA form applies: that form reads nothing else)
+    if ((!x && !x_bf16) || (!dy && !dy_bf16) || !dw || !workspace || batch < 1 || height < 2 || width < 2 || (height & 1) || (width & 1) ||
+        c_in < 1 || c_out < 1 || !aligned16(x_bf16) || !aligned16(dy_bf16)) {
         set_error("vaek_conv2d_weight_grad: invalid argument");
+        return VAEK_ERR_INVALID;
+    }
+    if ((!x || !dy) && !(conv_wgrad_fast(batch, height, width, c_in, c_out).ok && !(c_in == 1 && thin_channels_ok(c_out)))) {
+        set_error("vaek_conv2d_weight_grad: bf16-only tensors need the LDS-DMA kernel's shapes");
         return VAEK_ERR_INVALID;
     }
     ConvWArgs g{};
@@ -1061,12 +1106,45 @@ extern "C" int vaek_conv2d_bias_grad(const float* dy, float* dbias, void* worksp
     return launch_sum_slabs(static_cast<const float*>(workspace), c, S, dbias, c, st);
 }
 
+extern "C" int vaek_conv2d_bias_grad_bf16(const void* dy_bf16, float* dbias, void* workspace, int64_t pixels, int32_t c, void* stream) {
+    const long long n = pixels * (long long)c;
+    if (!dy_bf16 || !dbias || !workspace || pixels < 1 || c < 8 || (c & (c - 1)) || c > 2048 || n % 8 || !aligned16(dy_bf16)) {
+        set_error("vaek_conv2d_bias_grad_bf16: invalid argument (c a power of two in 8 .. 2048, 16-byte aligned)");
+        return VAEK_ERR_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const long long n8 = n / 8;
+    const int S8 = (int)std::min<long long>(512, (n8 + 1023) / 1024);
+    const long long chunk = ((n8 + S8 - 1) / S8 + 255) / 256 * 256;              // a multiple of 256 chunks: the column phase of a thread is fixed
+    {
+        ProfScope ps("conv_bias_grad", st);
+        launch_k(ps, conv_colsum8_bf16_kernel, dim3(S8), dim3(256), 0, st, static_cast<const uint4*>(dy_bf16), static_cast<float*>(workspace), n8, (int)c, chunk);
+        VAEK_HIP_CHECK(hipGetLastError());
+    }
+    return launch_sum_slabs_inplace(static_cast<float*>(workspace), c, S8, dbias, c, st);
+}
+
 extern "C" int vaek_conv2d_transpose_forward(const float* y, const float* w, const float* bias, const float* mask, float* out,
                                              int32_t batch, int32_t height, int32_t width, int32_t c_in, int32_t c_out, int32_t relu,
                                              void* workspace, const void* y_bf16, void* out_bf16, void* stream) {
-    if (!y || !w || !out || batch < 1 || height < 1 || width < 1 || c_in < 1 || c_out < 1 || !aligned16(y_bf16) || !aligned16(out_bf16)) {
+    // lean forms (see vaek.h): relu bit 1 = `mask` is the bf16 copy of the mask source; y / out may be null beside their bf16 copies
+    const bool mask_b16 = (relu & 2) != 0 && mask;
+    relu &= 1;
+    const void* mask16 = mask_b16 ? static_cast<const void*>(mask) : nullptr;
+    if (mask_b16) mask = nullptr;
+    const bool lean = !y || !out || mask_b16;
+    if ((!y && !y_bf16) || !w || (!out && !out_bf16) || batch < 1 || height < 1 || width < 1 || c_in < 1 || c_out < 1 || !aligned16(y_bf16) ||
+        !aligned16(out_bf16) || !aligned16(mask16)) {
         set_error("vaek_conv2d_transpose_forward: invalid argument");
         return VAEK_ERR_INVALID;
+    }
+    if (lean) {
+        const ConvFFast f = conv_fwd_fast(1, batch, height, width, c_in, c_out);
+        if (!(f.ok && workspace && aligned16(workspace) && aligned16(y) && aligned16(w) && aligned16(out) && aligned16(bias) && c_out != 1)) {
+            set_error("vaek_conv2d_transpose_forward: bf16-only tensors need the LDS-DMA kernel's shapes");
+            return VAEK_ERR_INVALID;
+        }
+        return conv_forward_fast(1, f, y, w, bias, mask, mask16, out, workspace, y_bf16, out_bf16, batch, height, width, c_in, c_out, relu != 0, (hipStream_t)stream);
     }
     ConvTArgs g{};
     g.y = y; g.w = w; g.bias = bias; g.mask = mask; g.out = out;
@@ -1091,7 +1169,7 @@ extern "C" int vaek_conv2d_transpose_forward(const float* y, const float* w, con
     }
     if (workspace && aligned16(workspace) && aligned16(y) && aligned16(w) && aligned16(out) && aligned16(mask) && aligned16(bias)) {
         const ConvFFast f = conv_fwd_fast(1, batch, height, width, c_in, c_out);
-        if (f.ok) return conv_forward_fast(1, f, y, w, bias, mask, out, workspace, y_bf16, out_bf16, batch, height, width, c_in, c_out, relu != 0, (hipStream_t)stream);
+        if (f.ok) return conv_forward_fast(1, f, y, w, bias, mask, nullptr, out, workspace, y_bf16, out_bf16, batch, height, width, c_in, c_out, relu != 0, (hipStream_t)stream);
     }
     g.M = (int)M; g.N = c_out; g.K = 4 * c_in; g.relu = relu;
     {
@@ -1110,10 +1188,24 @@ extern "C" int vaek_to_bf16(const float* src, void* dst_bf16, int64_t n, void* s
 extern "C" int vaek_conv2d_forward(const float* x, const float* w, const float* bias, const float* mask, float* y, int32_t batch,
                                    int32_t height, int32_t width, int32_t c_in, int32_t c_out, int32_t relu, void* workspace,
                                    const void* x_bf16, void* y_bf16, void* stream) {
-    if (!x || !w || !y || batch < 1 || height < 2 || width < 2 || (height & 1) || (width & 1) || c_in < 1 || c_out < 1 || !aligned16(x_bf16) ||
-        !aligned16(y_bf16)) {
+    // lean forms (see vaek.h): relu bit 1 = `mask` is the bf16 copy of the mask source; x / y may be null beside their bf16 copies
+    const bool mask_b16 = (relu & 2) != 0 && mask;
+    relu &= 1;
+    const void* mask16 = mask_b16 ? static_cast<const void*>(mask) : nullptr;
+    if (mask_b16) mask = nullptr;
+    if ((!x && !x_bf16) || !w || (!y && !y_bf16) || batch < 1 || height < 2 || width < 2 || (height & 1) || (width & 1) || c_in < 1 || c_out < 1 ||
+        !aligned16(x_bf16) || !aligned16(y_bf16) || !aligned16(mask16)) {
         set_error("vaek_conv2d_forward: invalid argument");
         return VAEK_ERR_INVALID;
+    }
+    const bool lean = !x || !y || mask_b16;
+    if (lean && !(c_in == 1 && thin_channels_ok(c_out))) {
+        const ConvFFast f = conv_fwd_fast(0, batch, height, width, c_in, c_out);
+        if (!(f.ok && workspace && aligned16(workspace) && aligned16(x) && aligned16(w) && aligned16(y) && aligned16(bias))) {
+            set_error("vaek_conv2d_forward: bf16-only tensors need the LDS-DMA kernel's shapes");
+            return VAEK_ERR_INVALID;
+        }
+        return conv_forward_fast(0, f, x, w, bias, mask, mask16, y, workspace, x_bf16, y_bf16, batch, height, width, c_in, c_out, relu != 0, (hipStream_t)stream);
     }
     ConvArgs g{};
     g.x = x; g.w = w; g.bias = bias; g.mask = mask; g.y = y;
@@ -1128,7 +1220,12 @@ extern "C" int vaek_conv2d_forward(const float* x, const float* w, const float* 
         {
             ProfScope ps("conv_fwd_thin", (hipStream_t)stream);
             const int hw = g.Ho * g.Wo;
-            if (by8 && c_out % 32 == 0 && (hw & (hw - 1)) == 0 && (g.Wo & (g.Wo - 1)) == 0) {
+            const bool mfma_form = by8 && c_out % 32 == 0 && (hw & (hw - 1)) == 0 && (g.Wo & (g.Wo - 1)) == 0;
+            if (lean && (!x || mask_b16 || !mfma_form)) {       // (the one-channel layer: only "no float32 result" is lean, and only on the matrix-core form)
+                set_error("vaek_conv2d_forward: the one-channel layer reads float32 and writes bf16-only on its matrix-core form alone");
+                return VAEK_ERR_INVALID;
+            }
+            if (mfma_form) {
                 ta.y16 = static_cast<__bf16*>(y_bf16);
                 launch_k(ps, thin_conv_fwd_mfma_kernel, dim3((unsigned)std::min<long long>(8192, (M / 32 + 3) / 4 + 1), c_out / 32), dim3(256), 0, (hipStream_t)stream,
                          ta, (int)relu, 31 - __builtin_clz(hw), 31 - __builtin_clz(g.Wo));
@@ -1144,7 +1241,7 @@ extern "C" int vaek_conv2d_forward(const float* x, const float* w, const float* 
     }
     if (workspace && aligned16(workspace) && aligned16(x) && aligned16(w) && aligned16(y) && aligned16(mask) && aligned16(bias)) {
         const ConvFFast f = conv_fwd_fast(0, batch, height, width, c_in, c_out);
-        if (f.ok) return conv_forward_fast(0, f, x, w, bias, mask, y, workspace, x_bf16, y_bf16, batch, height, width, c_in, c_out, relu != 0, (hipStream_t)stream);
+        if (f.ok) return conv_forward_fast(0, f, x, w, bias, mask, nullptr, y, workspace, x_bf16, y_bf16, batch, height, width, c_in, c_out, relu != 0, (hipStream_t)stream);
     }
     g.M = (int)M; g.N = c_out; g.K = 16 * c_in; g.relu = relu;
     {

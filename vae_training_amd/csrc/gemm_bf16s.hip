@@ -653,7 +653,8 @@ __global__ __launch_bounds__(2 * BM) void hs_tn_kernel(const HsDwArgs g) {
 enum { HC_FWD = 0, HC_T = 1 };
 struct HsConvArgs {
     const __bf16* X; const __bf16* Wb; const __bf16* zeros;
-    float* out; const float* bias; const float* mask; __bf16* out16;     // out16: optional bf16 copy of out (the next layer's operand)
+    float* out; const float* bias; const float* mask; __bf16* out16;     // out16: optional bf16 copy of out (the next layer's operand); out may be null when out16 is given
+    const __bf16* mask16;                     // the relu-mask source as its bf16 copy (instead of mask)
     int relu, H, W, Cin, Cout, M, N, K;       // H, W: the INPUT tensor's spatial size
     int sh_c, hw, wo;                         // log2 C_in; GEMM rows per image and per image row (FWD: Ho Wo, Wo; T: H W, W)
 };
@@ -751,13 +752,22 @@ __global__ __launch_bounds__(64 * WM * WN) void hs_conv_kernel(const HsConvArgs 
         }
     }
     float4 mk[kEarlyMask ? TM : 1][kEarlyMask ? TN : 1][4];
-    if (kEarlyMask && g.mask) {
+    auto mask_at = [&](long long e) {                      // four mask values at element e: float32, or the bf16 copy widened
+        if (g.mask16) {
+            const uint2 u = *reinterpret_cast<const uint2*>(g.mask16 + e);
+            return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                               __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+        }
+        return *reinterpret_cast<const float4*>(g.mask + e);
+    };
+    const bool masked = g.mask || g.mask16;
+    if (kEarlyMask && masked) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) mk[i][j][q] = *reinterpret_cast<const float4*>(g.mask + offs[i] + nbase + 32 * j + 8 * q + 4 * h);
+                for (int q = 0; q < 4; ++q) mk[i][j][q] = mask_at(offs[i] + nbase + 32 * j + 8 * q + 4 * h);
     }
 
     const int nt = g.K / BK;
@@ -804,11 +814,11 @@ __global__ __launch_bounds__(64 * WM * WN) void hs_conv_kernel(const HsConvArgs 
                     v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
                 }
                 v.x = fmaxf(v.x, floor_v); v.y = fmaxf(v.y, floor_v); v.z = fmaxf(v.z, floor_v); v.w = fmaxf(v.w, floor_v);
-                if (g.mask) {
-                    const float4 k4 = kEarlyMask ? mk[i][j][q] : *reinterpret_cast<const float4*>(g.mask + off + col);
+                if (masked) {
+                    const float4 k4 = kEarlyMask ? mk[i][j][q] : mask_at(off + col);
                     v.x = k4.x > 0.f ? v.x : 0.f; v.y = k4.y > 0.f ? v.y : 0.f; v.z = k4.z > 0.f ? v.z : 0.f; v.w = k4.w > 0.f ? v.w : 0.f;
                 }
-                *reinterpret_cast<float4*>(g.out + off + col) = v;
+                if (g.out) *reinterpret_cast<float4*>(g.out + off + col) = v;
                 if (g.out16) *reinterpret_cast<uint2*>(g.out16 + off + col) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
             }
     }
@@ -1012,10 +1022,10 @@ static int hs_conv_launch(const HsConvArgs& g, hipStream_t st) {
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
 }
-int launch_hs_conv(int mode, const __bf16* x, const __bf16* wb, const __bf16* zeros, const float* bias, const float* mask, float* out,
-                   __bf16* out16, int batch, int H, int W, int Cin, int Cout, bool relu, hipStream_t st) {
+int launch_hs_conv(int mode, const __bf16* x, const __bf16* wb, const __bf16* zeros, const float* bias, const float* mask, const __bf16* mask16,
+                   float* out, __bf16* out16, int batch, int H, int W, int Cin, int Cout, bool relu, hipStream_t st) {
     HsConvArgs g{};
-    g.X = x; g.Wb = wb; g.zeros = zeros; g.out = out; g.out16 = out16; g.bias = bias; g.mask = mask; g.relu = relu;
+    g.X = x; g.Wb = wb; g.zeros = zeros; g.out = out; g.out16 = out16; g.bias = bias; g.mask = mask; g.mask16 = mask16; g.relu = relu;
     g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.N = Cout; g.sh_c = 31 - __builtin_clz(Cin);
     if (mode == HC_FWD) { g.hw = (H / 2) * (W / 2); g.wo = W / 2; g.K = 16 * Cin; }
     else { g.hw = H * W; g.wo = W; g.K = 4 * Cin; }

@@ -239,8 +239,8 @@ int launch_sum_slabs_inplace(float* slabs, int64_t stride, int S, float* out, in
 #ifdef __HIPCC__
 int launch_cvt_bf16(const float* src, __bf16* dst, int64_t n, __bf16* zero8, hipStream_t st);
 int launch_cvt_bf16_t(const float* src, __bf16* dst, int K, int N, __bf16* zero8, hipStream_t st);
-int launch_hs_conv(int mode, const __bf16* x, const __bf16* wb, const __bf16* zeros, const float* bias, const float* mask, float* out,
-                   __bf16* out16, int batch, int H, int W, int Cin, int Cout, bool relu, hipStream_t st);      // mode 0: forward, 1: transposed
+int launch_hs_conv(int mode, const __bf16* x, const __bf16* wb, const __bf16* zeros, const float* bias, const float* mask, const __bf16* mask16,
+                   float* out, __bf16* out16, int batch, int H, int W, int Cin, int Cout, bool relu, hipStream_t st);      // mode 0: forward, 1: transposed
 int launch_hs_conv_dw(const __bf16* x, const __bf16* dy, const __bf16* zeros, float* slab0, int64_t slab_stride, int S, int rows_per_split,
                       int batch, int H, int W, int Cin, int Cout, hipStream_t st);
 #endif
