@@ -42,7 +42,9 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // on these loads is the kernels' own counted one (wait_tiles) in front of a barrier.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds_void_t*)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v) : "memory");
+    _Pragma("clang diagnostic push") _Pragma("clang diagnostic ignored \"-Winline-asm\"")      // (M0 on the clobber list: it is what the LDS-DMA takes its LDS address from)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v) : "memory", "m0");
+    _Pragma("clang diagnostic pop")
 }
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     const bf16x2 v = {(__bf16)lo, (__bf16)hi};

@@ -284,7 +284,9 @@ __global__ __launch_bounds__(256) void sk_last_bwd_kernel(const SkBwdArgs a) {
 // The waits are this kernel's own (counted) ones.
 __device__ __forceinline__ void sk_glds16(const void* gsrc, void* lds_wave_base) {
     const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds_void_t*)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v) : "memory");
+    _Pragma("clang diagnostic push") _Pragma("clang diagnostic ignored \"-Winline-asm\"")      // (M0 on the clobber list: it is what the LDS-DMA takes its LDS address from)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v) : "memory", "m0");
+    _Pragma("clang diagnostic pop")
 }
 template <int NT, bool FIRST = false>
 __global__ __launch_bounds__(256) void sk_last_bwd_mfma_kernel(const SkBwdArgs a) {
