@@ -189,6 +189,41 @@ def test_conv2d_bias_grad_sums_the_pixels(pixels, c):
     assert torch.equal(conv2d_bias_grad(_dev(dy)), conv2d_bias_grad(_dev(dy)))            # fixed-order sums
 
 
+@pytest.mark.parametrize("pixels,c", [(8 * 32 * 32, 32), (70000, 64), (16 * 16 * 3, 128), (1000, 8), (2048, 2048)])
+def test_conv2d_bias_grad_of_a_bf16_tensor(pixels, c):
+    """vaek_conv2d_bias_grad_bf16: float32 sums of the bf16 VALUES (the lean conv VAE's transposed-layer bias gradients), fixed order."""
+    from vae_training_amd.conv import conv2d_bias_grad
+    rng = np.random.default_rng(pixels + c)
+    dy16 = torch.from_numpy(np.asarray(rng.standard_normal((pixels, c)), np.float32)).cuda().to(torch.bfloat16).contiguous()
+    got = conv2d_bias_grad(dy16).cpu().numpy().astype(np.float64)
+    want = dy16.float().cpu().numpy().astype(np.float64).sum(axis=0)
+    assert np.max(np.abs(got - want)) <= 1e-5 * np.sqrt(pixels) * max(1.0, np.max(np.abs(want)) / np.sqrt(pixels))
+    assert torch.equal(conv2d_bias_grad(dy16), conv2d_bias_grad(dy16))
+
+
+def test_lean_forms_of_the_conv_entry_points():
+    """The bf16-only forms (NULL float32 tensor beside its bf16 copy, relu mask as a bf16 copy) give bitwise the bf16 results of the
+    float32-twin calls, and are refused (VAEK_ERR_INVALID) for shapes only the register-staged kernels cover."""
+    from vae_training_amd.conv import conv2d_forward, conv2d_transpose_forward, conv2d_weight_grad, to_bf16
+    g = torch.Generator(device="cpu").manual_seed(3)
+    B, H, Cin, Cout = 4, 16, 32, 64
+    x = torch.randn(B, H, H, Cin, generator=g).cuda(); K = (torch.randn(4, 4, Cin, Cout, generator=g) * 0.05).cuda()
+    m = torch.randn(B, H // 2, H // 2, Cout, generator=g).cuda()
+    x16, m16 = to_bf16(x), to_bf16(m)
+    y, y16 = conv2d_forward(x, K, None, True, mask=m, x16=x16, want16=True)
+    none, z16 = conv2d_forward(None, K, None, True, mask16=m16, x16=x16, want16=True, want32=False)
+    assert none is None and torch.equal(z16, y16)
+    t, t16 = conv2d_transpose_forward(y, K, None, False, mask=x, y16=y16, want16=True)
+    none, u16 = conv2d_transpose_forward(None, K, None, False, mask16=x16, y16=y16, want16=True, want32=False)
+    assert none is None and torch.equal(u16, t16)
+    dw, db = conv2d_weight_grad(x, y, x16=x16, dy16=y16)
+    dw2, db2 = conv2d_weight_grad(None, None, x16=x16, dy16=y16)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    xs = torch.randn(2, 6, 6, 3, generator=g).cuda(); Ks = torch.randn(4, 4, 3, 5, generator=g).cuda()      # register-staged shapes only
+    with pytest.raises(Exception):
+        conv2d_forward(None, Ks, None, False, x16=to_bf16(xs), want16=True, want32=False)
+
+
 def test_transposed_layer_backward_from_the_same_three_kernels():
     """conv_t_bwd of the oracle (d input, d kernel, d bias of the transposed layer) assembled from the HIP kernels:
     d input = conv2d_forward(d out, K), d kernel = conv2d_weight_grad(x := d out, dy := input) in the [4, 4, C_out, C_in] layout."""
