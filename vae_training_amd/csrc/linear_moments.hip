@@ -967,9 +967,32 @@ struct LinUpdM {
         if (t == 64 * (NB + 2)) scal[4] = (next_cnt && __hip_atomic_load(next_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= per_set) ? 1.0 : 0.0;
         const double eps = scal[0], sigma = scal[1], inv_var = scal[2], inv_bt = (double)a.inv_bt, c0 = inv_var * inv_bt;
         d4 sm[2], p1;
-        double sl[2][4], bl[2][4];
         double musq_p = 0.0, ssq_p = 0.0, z2r_p = 0.0;
         const int f = 16 * wave + j;                                   // chain waves: this lane's feature column
+        // The chain's WEIGHT operands (functions of the published parameters only) are read from LDS up front: left where they are
+        // used, hipcc issues each ds_read right in front of its MFMA and waits for it -- ds_read, s_waitcnt lgkmcnt(0), v_mfma, 17
+        // times: an LDS round trip (~130 cycles) on top of every 64-cycle product of the dependent chain.
+        // (SM's and P1's weights here; G's and the dWd wave's operands in ONE batch behind the barrier: held across it they spill)
+        double awSMr[KD][2], awP1r[4 + (RL1 ? RL1 : 1)];
+        auto awSM = [&](int kk, int lt) -> double& { return awSMr[kk][lt]; };
+        auto awP1 = [&](int r) -> double& { return awP1r[r]; };
+        if (wave < NB) {
+#pragma unroll
+            for (int kk = 0; kk < KD; ++kk)
+#pragma unroll
+                for (int lt = 0; lt < 2; ++lt) {
+                    const int dd = 4 * kk + g, l = 16 * lt + j;
+                    const double w1 = Wed[min(dd, D - 1) * L + min(l, L - 1)];
+                    awSM(kk, lt) = (dd < D && l < L && (lt == 0 || RL1 > 0)) ? w1 : 0.0;
+                }
+#pragma unroll
+            for (int r = 0; r < 4 + RL1; ++r) {
+                const int l = (r < 4 ? 4 * r : 16 + 4 * (r - 4)) + g;
+                const double w = Wdd[min(l, L - 1) * D + min(j, D - 1)];
+                awP1(r) = (j < D && l < L) ? w : 0.0;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (wave < NB) {
             const double* Mz = mreg; const double* Mx = mreg + 4 + RL1; const double* Mz2 = Mx + KD; const double Mone = mreg[NM - 1];
             // ---- SM ----
@@ -979,18 +1002,16 @@ struct LinUpdM {
                 for (int r = 0; r < 4; ++r) {
                     const int l = 16 * lt + g + 4 * r;
                     const bool ok = l < L && (lt == 0 || r < RL1);
-                    sl[lt][r] = ok ? sd[min(l, L - 1)] : 0.0; bl[lt][r] = ok ? bed[min(l, L - 1)] : 0.0;
-                    sm[lt][r] = (lt == 0 || r < RL1) ? sl[lt][r] * Mz[lt == 0 ? r : min(4 + r, 3 + RL1)] + bl[lt][r] * Mone : 0.0;
+                    const double sv = sd[min(l, L - 1)], bv = bed[min(l, L - 1)];
+                    const double slv = ok ? sv : 0.0, blv = ok ? bv : 0.0;
+                    sm[lt][r] = (lt == 0 || r < RL1) ? slv * Mz[lt == 0 ? r : min(4 + r, 3 + RL1)] + blv * Mone : 0.0;
                 }
 #pragma unroll
             for (int kk = 0; kk < KD; ++kk) {
-                const int dd = 4 * kk + g;
 #pragma unroll
                 for (int lt = 0; lt < 2; ++lt) {
                     if (lt == 1 && RL1 == 0) continue;
-                    const int l = 16 * lt + j;
-                    const double aw = (dd < D && l < L) ? Wed[min(dd, D - 1) * L + min(l, L - 1)] : 0.0;
-                    sm[lt] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, Mx[kk], sm[lt], 0, 0, 0);
+                    sm[lt] = __builtin_amdgcn_mfma_f64_16x16x4f64(awSM(kk, lt), Mx[kk], sm[lt], 0, 0, 0);
                 }
             }
             // ---- P1 ----
@@ -1000,17 +1021,9 @@ struct LinUpdM {
                 p1[r] = (r < KD && d < D) ? -Mx[min(r, KD - 1)] + sigma * Mz2[min(r, KD - 1)] + bdd[min(d, D - 1)] * Mone : 0.0;
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int l = 4 * r + g;
-                const double aw = (j < D && l < L) ? Wdd[min(l, L - 1) * D + min(j, D - 1)] : 0.0;
-                p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, sm[0][r], p1, 0, 0, 0);
-            }
+            for (int r = 0; r < 4; ++r) p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(awP1(r), sm[0][r], p1, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < RL1; ++r) {
-                const int l = 16 + 4 * r + g;
-                const double aw = (j < D && l < L) ? Wdd[min(l, L - 1) * D + min(j, D - 1)] : 0.0;
-                p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, sm[1][r], p1, 0, 0, 0);
-            }
+            for (int r = 0; r < RL1; ++r) p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(awP1(4 + r), sm[1][r], p1, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) P1s[(g + 4 * r) * NFP + f] = p1[r];
         } else if (wave == NB + 1) {
@@ -1029,18 +1042,35 @@ struct LinUpdM {
         have_next = scal[4] != 0.0;
         if (wave < NB) {
             if (have_next) fetch_M(M_next, mnext);
-            // ---- G = Wd P1 ----
+            // ---- G = Wd P1 ---- (its six weights in one batch of LDS reads first)
+            double awGr[KD][2];
+#pragma unroll
+            for (int kk = 0; kk < KD; ++kk)
+#pragma unroll
+                for (int lt = 0; lt < 2; ++lt) {
+                    const int dd = 4 * kk + g, l = 16 * lt + j;
+                    const double w2 = Wdd[min(l, L - 1) * D + min(dd, D - 1)];
+                    awGr[kk][lt] = (l < L && dd < D && (lt == 0 || RL1 > 0)) ? w2 : 0.0;
+                }
+            double sl[2][4], bl[2][4];                                 // (read again: held across the barrier they spill)
+#pragma unroll
+            for (int lt = 0; lt < 2; ++lt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int l = 16 * lt + g + 4 * r;
+                    const bool ok = l < L && (lt == 0 || r < RL1);
+                    const double sv = sd[min(l, L - 1)], bv = bed[min(l, L - 1)];
+                    sl[lt][r] = ok ? sv : 0.0; bl[lt][r] = ok ? bv : 0.0;
+                }
+            __builtin_amdgcn_sched_barrier(0);
             d4 G[2];
             G[0] = d4{0.0, 0.0, 0.0, 0.0}; G[1] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int r = 0; r < KD; ++r) {
-                const int d = 4 * r + g;
 #pragma unroll
                 for (int lt = 0; lt < 2; ++lt) {
                     if (lt == 1 && RL1 == 0) continue;
-                    const int l = 16 * lt + j;
-                    const double aw = (l < L && d < D) ? Wdd[min(l, L - 1) * D + min(d, D - 1)] : 0.0;
-                    G[lt] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, p1[r], G[lt], 0, 0, 0);
+                    G[lt] = __builtin_amdgcn_mfma_f64_16x16x4f64(awGr[r][lt], p1[r], G[lt], 0, 0, 0);
                 }
             }
             // ---- the gradients that are elements of these tiles ----
@@ -1090,26 +1120,48 @@ struct LinUpdM {
             if (lane == 0) { part[3 * wave] = ssq_p; part[3 * wave + 1] = musq_p; part[3 * wave + 2] = z2r_p; }
         } else if (wave == NB) {
             // ---- dwd^T[d][l] = s_l P1[d][l] + be_l P1[d][one] + sum_dd P1[d][x_dd] We[dd][l]  (rows d = g + 4 r, columns l = 16 ct + j) ----
+            // (every LDS operand first -- We was read in front of the barrier --, then the products back to back: see the chain waves)
             d4 C[2];
-            double wsum = 0.0;
+            double wsum = 0.0, avk[KD], p1l[2][4], p1o[4], dw_sr[2], dw_br[2], dw_wr[KD][2], dw_dr[2][4];
+            auto dw_s = [&](int ct) -> double& { return dw_sr[ct]; };
+            auto dw_b = [&](int ct) -> double& { return dw_br[ct]; };
+            auto dw_w = [&](int kk, int ct) -> double& { return dw_wr[kk][ct]; };
+            auto dw_d = [&](int ct, int r) -> double& { return dw_dr[ct][r]; };
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
-                if (ct == 1 && RL1 == 0) continue;
                 const int l = 16 * ct + j, lc = min(l, L - 1);
-                const double s_l = l < L ? sd[lc] : 0.0, b_l = l < L ? bed[lc] : 0.0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) C[ct][r] = s_l * P1s[(g + 4 * r) * NFP + lc] + b_l * P1s[(g + 4 * r) * NFP + fone];
+                const double s_l = sd[lc], b_l = bed[lc];
+                dw_s(ct) = l < L ? s_l : 0.0; dw_b(ct) = l < L ? b_l : 0.0;
 #pragma unroll
                 for (int kk = 0; kk < KD; ++kk) {
                     const int dd = 4 * kk + g;
-                    const double av = P1s[j * NFP + min(L + dd, NFP - 1)];
-                    const double bv = (dd < D && l < L) ? Wed[min(dd, D - 1) * L + lc] : 0.0;
-                    C[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, C[ct], 0, 0, 0);
+                    const double w = Wed[min(dd, D - 1) * L + lc];
+                    dw_w(kk, ct) = (dd < D && l < L) ? w : 0.0;
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dw_d(ct, r) = Wdd[lc * D + min(g + 4 * r, D - 1)];
+            }
+#pragma unroll
+            for (int kk = 0; kk < KD; ++kk) avk[kk] = P1s[j * NFP + min(L + 4 * kk + g, NFP - 1)];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p1o[r] = P1s[(g + 4 * r) * NFP + fone];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) p1l[ct][r] = P1s[(g + 4 * r) * NFP + min(16 * ct + j, L - 1)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                if (ct == 1 && RL1 == 0) continue;
+                const int l = 16 * ct + j;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) C[ct][r] = dw_s(ct) * p1l[ct][r] + dw_b(ct) * p1o[r];
+#pragma unroll
+                for (int kk = 0; kk < KD; ++kk) C[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(avk[kk], dw_w(kk, ct), C[ct], 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int d = g + 4 * r;
-                    if (l < L && d < D) { gq[off_wd + l * D + d] = c0 * C[ct][r]; wsum += Wdd[l * D + d] * C[ct][r]; }
+                    if (l < L && d < D) { gq[off_wd + l * D + d] = c0 * C[ct][r]; wsum += dw_d(ct, r) * C[ct][r]; }
                 }
             }
             wsum = lin_wave_sum(wsum);
