@@ -39,10 +39,13 @@ class ConvVAE:
         come from the bf16 copies, the transposed layers' bias gradients are column sums of the bf16 gradient.  Every product reads
         the same bf16 operands either way, so all leaves but those bias gradients are bitwise the same as with lean=False
         (tests/test_gpu_conv.py).  Needs the LDS-DMA kernels' shapes (power-of-two widths in 32 .. 256, power-of-two image): other
-        models run as before."""
+        models run as before.  lean=2 (the default): the two 32-channel images at the one-channel ends too -- the last transposed
+        layer's input and the gradient reaching the first convolution's kernel gradient -- so the streaming one-channel kernels read
+        bf16 copies like every other layer does (the model's arithmetic changes there: the bf16 envelope, not bitwise)."""
         assert size % 16 == 0 and len(widths) == 4
         self.lean = bool(lean) and all(32 <= w <= 256 and (w & (w - 1)) == 0 for w in widths) and (size & (size - 1)) == 0 and \
             batch * (size // 16) ** 2 >= 64
+        self.lean2 = self.lean and (lean is True or int(lean) >= 2) and size % 8 == 0
         self.world = int(world)
         self.B, self.S, self.widths, self.L, self.eps_cli, self.tdv = batch, size, tuple(widths), latent_dim, float(epsilon), tunable_decoder_var
         self.bott = (size // 16) ** 2 * widths[3]
@@ -90,7 +93,7 @@ class ConvVAE:
         G = lambda n: self.view(grads, n)
         # ---- forward (every tensor a bf16-operand kernel will read again gets its bf16 copy from the epilogue that produces it; lean:
         # the hidden ones get NOTHING else -- acts[1..3], dec[1..2] and the gradients below are None beside their bf16 copies)
-        lean = self.lean
+        lean, lean2 = self.lean, self.lean2
         acts, acts16 = [x], [None]
         for i in range(4):
             y, y16 = _pair(conv2d_forward(acts[-1], P(f"Encoder/Conv{i}/kernel"), P(f"Encoder/Conv{i}/bias"), relu=True, x16=acts16[-1], want16=i < 3,
@@ -103,7 +106,7 @@ class ConvVAE:
         dec16 = [to_bf16(dec[0])]
         for i in range(4):
             y, y16 = _pair(conv2d_transpose_forward(dec[-1], P(f"Decoder/ConvT{i}/kernel"), P(f"Decoder/ConvT{i}/bias"), relu=i < 3,
-                                                    y16=dec16[-1], want16=i < 2, want32=not (lean and i < 2)))
+                                                    y16=dec16[-1], want16=i < 2 or (lean2 and i == 2), want32=not (lean and i < 2) and not (lean2 and i == 2)))
             dec.append(y); dec16.append(y16)
         bt = B * self.world                                                                       # the means' denominator: the GLOBAL batch
         out4, d, _ = e.elbo_fwd_bwd(x.view(B, S * S), dec[4].view(B, S * S), None, z2.view(B, S * S), mu, lv, self.eps_cli, batch_total=bt,
@@ -133,7 +136,7 @@ class ConvVAE:
             if i > 0:
                 m16 = inp16 if lean else None
                 d, d16 = _pair(conv2d_transpose_forward(d, P(f"Encoder/Conv{i}/kernel"), None, relu=False, mask=None if m16 is not None else inp, mask16=m16,
-                                                        y16=d16, want16=i > 1, want32=not (lean and i > 1)))
+                                                        y16=d16, want16=i > 1 or lean2, want32=not (lean and i > 1) and not lean2))
         if self.tdv:
             G("epsilon").copy_(out4[3:4] * self.eps_cli)                                          # eps = param * eps_cli
         return out4

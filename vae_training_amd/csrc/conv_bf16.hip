@@ -495,6 +495,9 @@ static int conv_wgrad_splits(long long pixels, int M, int N) {
 struct ThinArgs {
     const float* x; const float* w; const float* bias; const float* mask; float* y; __bf16* y16;
     int B, H, W, C, Ho, Wo; long long pixels;          // C: the wide side's channel count
+    // lean forms (round 3): the WIDE tensor as its bf16 copy instead -- x16: the transposed forward's input (4s kernel); mask16: the
+    // forward's relu-mask source / the kernel gradient's dy (matrix-core forms)
+    const __bf16* x16; const __bf16* mask16;
 };
 // forward, C_in = 1: y[p, o] = act(b[o] + sum_taps x_window[p, tap] K[tap, o]).  Thread = (pixel lane, o); C | 256.
 __global__ __launch_bounds__(256) void thin_conv_fwd_kernel(const ThinArgs g, const int relu) {
@@ -614,6 +617,8 @@ __global__ __launch_bounds__(256) void thin_conv_t_fwd4_kernel(const ThinArgs g,
 // The strip form (input width a multiple of 4): C / 4 lanes take FOUR input pixels of a row at once -- 3 x 6 neighbourhood loads for 16
 // outputs instead of 4 x 9, one index decode and one set of row / column bounds per strip.  (The one-pixel form above spent 290
 // instructions per lane and pixel, most of them addresses and bounds: it ran at 1.7 TB/s with its traffic already at the minimum.)
+// X16: the input is read from its bf16 copy (a compile-time choice: a load under a run-time condition is a wait where it is issued)
+template <bool X16>
 __global__ __launch_bounds__(256) void thin_conv_t_fwd4s_kernel(const ThinArgs g, const int relu) {
     const int C = g.C, LP = C / 4, SW = g.W / 4;         // strips per input row
     unsigned lb = blockIdx.x;
@@ -635,12 +640,18 @@ __global__ __launch_bounds__(256) void thin_conv_t_fwd4s_kernel(const ThinArgs g
         for (int r = 0; r < 3; ++r) {
             const int yy = i - 1 + r;
             const bool rv = yy >= 0 && yy < g.H;
-            const float* rowp = g.x + ((long long)n * g.H + min(max(yy, 0), g.H - 1)) * g.W * C + 4 * lg;
+            const long long rowo = ((long long)n * g.H + min(max(yy, 0), g.H - 1)) * g.W * C + 4 * lg;
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
                 const int xx = j0 - 1 + c;
                 const bool in = rv && xx >= 0 && xx < g.W;
-                const float4 f = *reinterpret_cast<const float4*>(rowp + (long long)min(max(xx, 0), g.W - 1) * C);
+                const long long eo = rowo + (long long)min(max(xx, 0), g.W - 1) * C;
+                float4 f;
+                if constexpr (X16) {                        // (four bf16 widened)
+                    const uint2 u = *reinterpret_cast<const uint2*>(g.x16 + eo);
+                    f = make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                                    __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+                } else f = *reinterpret_cast<const float4*>(g.x + eo);
                 v[r][c] = in ? f : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -814,6 +825,7 @@ __global__ __launch_bounds__(256) void thin_conv_wgrad8_kernel(const ThinArgs g,
 // row of ones, N = C, K = pixels; v_mfma_f32_32x32x2_f32 takes two pixels per instruction -- lane (i, k) supplies x at tap i of pixel k
 // (one gathered dword), lane (j, k) supplies dy[pixel k][j] (a coalesced row) -- and the 17 x 8 accumulators per thread of the VALU
 // form become 16 registers per lane, so many more waves stream at once.  blockIdx.y = the block of 32 channels.
+template <bool DY16>                                     // dy read from its bf16 copy (compile-time, as above)
 __global__ __launch_bounds__(256) void thin_conv_wgrad_mfma_kernel(const ThinArgs g, float* part, const int sh_hw, const int sh_w) {
     __shared__ float red[4][17 * 32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, k = lane >> 5, c0 = blockIdx.y * 32;
@@ -838,7 +850,12 @@ __global__ __launch_bounds__(256) void thin_conv_wgrad_mfma_kernel(const ThinArg
             const long long qq = q + 4 * u, p = min(2 * qq + k, g.pixels - 1);
             const bool live = qq < q1 && 2 * qq + k < g.pixels;
             av[u] = a_val(p, live);
-            const float d = g.mask[p * g.C + c0 + i];
+            // (bf16: a DWORD per lane -- channel pair i & ~1 -- and this lane's half of it: 2-byte loads measured 60 % slower than the float32 ones)
+            float d;
+            if constexpr (DY16) {
+                const unsigned w2 = reinterpret_cast<const unsigned*>(g.mask16)[(p * g.C + c0 + i) >> 1];
+                d = __builtin_bit_cast(float, (i & 1) ? (w2 & 0xffff0000u) : (w2 << 16));
+            } else d = g.mask[p * g.C + c0 + i];
             bv[u] = live ? d : 0.f;
         }
 #pragma unroll
@@ -860,6 +877,7 @@ __global__ __launch_bounds__(256) void thin_conv_wgrad_mfma_kernel(const ThinArg
 // columns = 32 channels; 8 gathered dwords per lane feed 8 v_mfma_f32_32x32x2_f32, the 16 x 32 weights of the channel block sit in 8
 // registers, and a result register is one pixel's 32 channels across 32 lanes -- 128-byte rows for the stores, the mask and the bf16
 // copy.  ~50 VGPRs instead of 190: four times the waves, i.e. the bytes in flight this HBM-bound layer was missing.
+template <bool M16>                                      // the relu-mask source read from its bf16 copy (compile-time, as above)
 __global__ __launch_bounds__(256) void thin_conv_fwd_mfma_kernel(const ThinArgs g, const int relu, const int sh_hw, const int sh_w) {
     const int lane = threadIdx.x & 63, i = lane & 31, kk = lane >> 5, c0 = blockIdx.y * 32;
     float bw[8];
@@ -880,7 +898,14 @@ __global__ __launch_bounds__(256) void thin_conv_fwd_mfma_kernel(const ThinArgs 
             av[s2] = in ? v : 0.f;
         }
         float mk[16];
-        if (g.mask) {
+        const bool masked = g.mask || g.mask16;
+        if constexpr (M16) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned w2 = reinterpret_cast<const unsigned*>(g.mask16)[(min(p0 + (r & 3) + 8 * (r >> 2) + 4 * kk, g.pixels - 1) * g.C + c0 + i) >> 1];
+                mk[r] = __builtin_bit_cast(float, (i & 1) ? (w2 & 0xffff0000u) : (w2 << 16));
+            }
+        } else if (g.mask) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mk[r] = g.mask[min(p0 + (r & 3) + 8 * (r >> 2) + 4 * kk, g.pixels - 1) * g.C + c0 + i];
         }
@@ -894,7 +919,7 @@ __global__ __launch_bounds__(256) void thin_conv_fwd_mfma_kernel(const ThinArgs 
             const long long q = p0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
             float v = acc[r];
             if (relu) v = fmaxf(v, 0.f);
-            if (g.mask) v = mk[r] > 0.f ? v : 0.f;
+            if (masked) v = mk[r] > 0.f ? v : 0.f;
             const float nb = __shfl_down(v, 1, 64);        // the odd neighbour's channel: even lanes store bf16 pairs
             if (q < g.pixels) {
                 if (g.y) g.y[q * g.C + c0 + i] = v;
@@ -1008,9 +1033,12 @@ extern "C" int vaek_conv2d_weight_grad(const float* x, const float* dy, float* d
         set_error("vaek_conv2d_weight_grad: invalid argument");
         return VAEK_ERR_INVALID;
     }
-    if ((!x || !dy) && !(conv_wgrad_fast(batch, height, width, c_in, c_out).ok && !(c_in == 1 && thin_channels_ok(c_out)))) {
-        set_error("vaek_conv2d_weight_grad: bf16-only tensors need the LDS-DMA kernel's shapes");
-        return VAEK_ERR_INVALID;
+    {
+        const int hw_ = (height / 2) * (width / 2), wo_ = width / 2;
+        const bool thin = c_in == 1 && thin_channels_ok(c_out);
+        const bool thin_mfma = thin && c_out % 32 == 0 && (hw_ & (hw_ - 1)) == 0 && (wo_ & (wo_ - 1)) == 0;
+        const bool ok = thin ? (x && (dy || thin_mfma)) : (conv_wgrad_fast(batch, height, width, c_in, c_out).ok || (x && dy));
+        if (!ok) { set_error("vaek_conv2d_weight_grad: bf16-only tensors need the LDS-DMA (or, one channel: the matrix-core) kernel's shapes"); return VAEK_ERR_INVALID; }
     }
     ConvWArgs g{};
     g.x = x; g.dy = dy; g.slab = static_cast<float*>(workspace);
@@ -1020,7 +1048,7 @@ extern "C" int vaek_conv2d_weight_grad(const float* x, const float* dy, float* d
     hipStream_t st0 = (hipStream_t)stream;
     if (c_in == 1 && thin_channels_ok(c_out)) {           // one-channel gathered tensor: a streaming kernel, exact f32
         ThinArgs ta{};
-        ta.x = x; ta.mask = dy;
+        ta.x = x; ta.mask = dy; ta.mask16 = dy ? nullptr : static_cast<const __bf16*>(dy_bf16);       // (dy NULL: its bf16 copy, matrix-core form)
         ta.B = batch; ta.H = height; ta.W = width; ta.C = c_out; ta.Ho = g.Ho; ta.Wo = g.Wo; ta.pixels = pixels;
         float* part = static_cast<float*>(workspace);
         const int nb = (int)std::min<long long>(kThinWgradBlocks, (pixels + 255) / 256);
@@ -1028,7 +1056,7 @@ extern "C" int vaek_conv2d_weight_grad(const float* x, const float* dy, float* d
             ProfScope ps("conv_wgrad_thin", st0);
             const int hw = g.Ho * g.Wo;
             if (c_out % 32 == 0 && (hw & (hw - 1)) == 0 && (g.Wo & (g.Wo - 1)) == 0)
-                launch_k(ps, thin_conv_wgrad_mfma_kernel, dim3(nb, c_out / 32), dim3(256), 0, st0, ta, part, 31 - __builtin_clz(hw), 31 - __builtin_clz(g.Wo));
+                launch_k(ps, ta.mask16 ? thin_conv_wgrad_mfma_kernel<true> : thin_conv_wgrad_mfma_kernel<false>, dim3(nb, c_out / 32), dim3(256), 0, st0, ta, part, 31 - __builtin_clz(hw), 31 - __builtin_clz(g.Wo));
             else if (thin_groups_ok(c_out) && aligned16(dy)) launch_k(ps, thin_conv_wgrad8_kernel, dim3(nb), dim3(256), (size_t)4 * 17 * c_out * sizeof(float), st0, ta, part);
             else launch_k(ps, thin_conv_wgrad_kernel, dim3(nb), dim3(256), 0, st0, ta, part);
             VAEK_HIP_CHECK(hipGetLastError());
@@ -1138,6 +1166,19 @@ extern "C" int vaek_conv2d_transpose_forward(const float* y, const float* w, con
         set_error("vaek_conv2d_transpose_forward: invalid argument");
         return VAEK_ERR_INVALID;
     }
+    const bool thin4s = c_out == 1 && c_in % 4 == 0 && c_in <= 256 && (c_in & (c_in - 1)) == 0 && width % 4 == 0 && aligned16(w) && aligned16(out) && aligned16(mask);
+    if (lean && thin4s && out && !mask_b16) {             // the one-channel layer reading the bf16 copy of its input (the 4s kernel only)
+        const long long M = (long long)batch * height * width;
+        ThinArgs ta{};
+        ta.x = y; ta.x16 = static_cast<const __bf16*>(y_bf16); ta.w = w; ta.bias = bias; ta.mask = mask; ta.y = out;
+        ta.B = batch; ta.H = height; ta.W = width; ta.C = c_in; ta.pixels = 4 * M;
+        {
+            ProfScope ps("conv_t_fwd_thin", (hipStream_t)stream);
+            launch_k(ps, ta.x16 ? thin_conv_t_fwd4s_kernel<true> : thin_conv_t_fwd4s_kernel<false>, dim3((unsigned)std::min<long long>(8192, (M / 4 * (c_in / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
+            VAEK_HIP_CHECK(hipGetLastError());
+        }
+        return out_bf16 ? launch_cvt_bf16(out, static_cast<__bf16*>(out_bf16), 4 * M, nullptr, (hipStream_t)stream) : VAEK_OK;
+    }
     if (lean) {
         const ConvFFast f = conv_fwd_fast(1, batch, height, width, c_in, c_out);
         if (!(f.ok && workspace && aligned16(workspace) && aligned16(y) && aligned16(w) && aligned16(out) && aligned16(bias) && c_out != 1)) {
@@ -1158,7 +1199,7 @@ extern "C" int vaek_conv2d_transpose_forward(const float* y, const float* w, con
         {
             ProfScope ps("conv_t_fwd_thin", (hipStream_t)stream);
             if ((c_in & (c_in - 1)) == 0 && width % 4 == 0 && aligned16(out) && aligned16(mask))
-                launch_k(ps, thin_conv_t_fwd4s_kernel, dim3((unsigned)std::min<long long>(8192, (M / 4 * (c_in / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
+                launch_k(ps, thin_conv_t_fwd4s_kernel<false>, dim3((unsigned)std::min<long long>(8192, (M / 4 * (c_in / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
             else if ((c_in & (c_in - 1)) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0 && (reinterpret_cast<uintptr_t>(mask) & 7) == 0)
                 launch_k(ps, thin_conv_t_fwd4_kernel, dim3((unsigned)std::min<long long>(8192, (M * (c_in / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ta, (int)relu);
             else
@@ -1221,13 +1262,14 @@ extern "C" int vaek_conv2d_forward(const float* x, const float* w, const float* 
             ProfScope ps("conv_fwd_thin", (hipStream_t)stream);
             const int hw = g.Ho * g.Wo;
             const bool mfma_form = by8 && c_out % 32 == 0 && (hw & (hw - 1)) == 0 && (g.Wo & (g.Wo - 1)) == 0;
-            if (lean && (!x || mask_b16 || !mfma_form)) {       // (the one-channel layer: only "no float32 result" is lean, and only on the matrix-core form)
-                set_error("vaek_conv2d_forward: the one-channel layer reads float32 and writes bf16-only on its matrix-core form alone");
+            if (lean && (!x || !mfma_form)) {                   // (the one-channel layer: x stays float32; the lean forms on the matrix-core form only)
+                set_error("vaek_conv2d_forward: the one-channel layer reads a float32 x, and its lean forms need the matrix-core kernel's shapes");
                 return VAEK_ERR_INVALID;
             }
             if (mfma_form) {
                 ta.y16 = static_cast<__bf16*>(y_bf16);
-                launch_k(ps, thin_conv_fwd_mfma_kernel, dim3((unsigned)std::min<long long>(8192, (M / 32 + 3) / 4 + 1), c_out / 32), dim3(256), 0, (hipStream_t)stream,
+                ta.mask16 = static_cast<const __bf16*>(mask16);
+                launch_k(ps, ta.mask16 ? thin_conv_fwd_mfma_kernel<true> : thin_conv_fwd_mfma_kernel<false>, dim3((unsigned)std::min<long long>(8192, (M / 32 + 3) / 4 + 1), c_out / 32), dim3(256), 0, (hipStream_t)stream,
                          ta, (int)relu, 31 - __builtin_clz(hw), 31 - __builtin_clz(g.Wo));
             } else if (by8) {
                 ta.y16 = static_cast<__bf16*>(y_bf16);
