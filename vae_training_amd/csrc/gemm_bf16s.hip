@@ -659,6 +659,8 @@ struct HsConvArgs {
     const __bf16* mask16;                     // the relu-mask source as its bf16 copy (instead of mask)
     int relu, H, W, Cin, Cout, M, N, K;       // H, W: the INPUT tensor's spatial size
     int sh_c, hw, wo;                         // log2 C_in; GEMM rows per image and per image row (FWD: Ho Wo, Wo; T: H W, W)
+    int sh_hw, sh_wo;                         // their log2 where they are powers of two (else -1): a run-time integer division is ~35 vector
+                                              // instructions, and a thread of the 256-row tile did twenty of them in front of four k-tiles
 };
 template <int MODE, int BN, int WM, int WN, int BK, int NS, int BM = 128>
 __global__ __launch_bounds__(64 * WM * WN) void hs_conv_kernel(const HsConvArgs g) {
@@ -683,13 +685,17 @@ __global__ __launch_bounds__(64 * WM * WN) void hs_conv_kernel(const HsConvArgs 
     const int wm = wv / WN, wn = wv % WN;
     auto swz = [](int row) { return BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; };
     const int cmask = g.Cin - 1;
+    const bool pow2 = g.sh_hw >= 0 && g.sh_wo >= 0;      // (uniform: config 5's image sizes)
 
     int a_n[A_PASSES], a_y[A_PASSES], a_x[A_PASSES], a_c[A_PASSES];
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
         const int p = i * NTH + t, row = p / CPR;
         a_c[i] = ((p % CPR) ^ swz(row)) * 8;
-        const int m = min(m0 + row, g.M - 1), n = m / g.hw, ij = m % g.hw, ii = ij / g.wo, jj = ij % g.wo;
+        const int m = min(m0 + row, g.M - 1);
+        int n, ij, ii, jj;
+        if (pow2) { n = m >> g.sh_hw; ij = m & (g.hw - 1); ii = ij >> g.sh_wo; jj = ij & (g.wo - 1); }
+        else { n = m / g.hw; ij = m % g.hw; ii = ij / g.wo; jj = ij % g.wo; }
         a_n[i] = n * g.H * g.W;
         a_y[i] = MODE == HC_FWD ? 2 * ii - 1 : ii + pp;
         a_x[i] = MODE == HC_FWD ? 2 * jj - 1 : jj + qq;
@@ -749,7 +755,9 @@ __global__ __launch_bounds__(64 * WM * WN) void hs_conv_kernel(const HsConvArgs 
         const int m = min(m0 + wm * (BM / WM) + i * 32 + r, g.M - 1);
         if (MODE == HC_FWD) offs[i] = (long long)m * g.N;
         else {
-            const int n = m / g.hw, ij = m % g.hw, ii = ij / g.wo, jj = ij % g.wo;
+            int n, ij, ii, jj;
+            if (pow2) { n = m >> g.sh_hw; ij = m & (g.hw - 1); ii = ij >> g.sh_wo; jj = ij & (g.wo - 1); }
+            else { n = m / g.hw; ij = m % g.hw; ii = ij / g.wo; jj = ij % g.wo; }
             offs[i] = (((long long)n * 2 * g.H + 2 * ii + pp) * 2 * g.W + 2 * jj + qq) * g.N;
         }
     }
@@ -1031,6 +1039,8 @@ int launch_hs_conv(int mode, const __bf16* x, const __bf16* wb, const __bf16* ze
     g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.N = Cout; g.sh_c = 31 - __builtin_clz(Cin);
     if (mode == HC_FWD) { g.hw = (H / 2) * (W / 2); g.wo = W / 2; g.K = 16 * Cin; }
     else { g.hw = H * W; g.wo = W; g.K = 4 * Cin; }
+    g.sh_hw = g.hw > 0 && (g.hw & (g.hw - 1)) == 0 ? 31 - __builtin_clz(g.hw) : -1;
+    g.sh_wo = g.wo > 0 && (g.wo & (g.wo - 1)) == 0 ? 31 - __builtin_clz(g.wo) : -1;
     const long long M = (long long)batch * g.hw;
     if ((Cin & (Cin - 1)) || Cout % 32 || g.K % 64 || M > 0x7fffffffll || (long long)batch * H * W > 0x7fffffffll) {
         set_error("convolution on the bf16-storage loader: unsupported shape");
