@@ -490,11 +490,11 @@ int mlp1_launch(vaek_ctx* c, const float* params, const float* x, const float* z
     const bool big = D > 8 || L > 8, sig = c->cfg.sigmoid_decoder != 0;
     const Mlp1Kernel fn = big ? (sig ? mlp1_fused_kernel<16, 16, true> : mlp1_fused_kernel<16, 16, false>)
                               : (sig ? mlp1_fused_kernel<8, 8, true> : mlp1_fused_kernel<8, 8, false>);
-    static thread_local bool attr_set[4] = {};
+    static thread_local PerDeviceOnce attr_set[4];
     const int vi = (big ? 2 : 0) + (sig ? 1 : 0);
-    if (!attr_set[vi]) {
+    if (attr_set[vi].need()) {
         VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Mlp1Lds)));
-        attr_set[vi] = true;
+        attr_set[vi].mark();
     }
     ProfScope ps("fused_mlp1_fwd_bwd", st);
     launch_k(ps, fn, dim3((unsigned)mlp1_grid(c)), dim3(M1_NT), sizeof(Mlp1Lds), st, a);

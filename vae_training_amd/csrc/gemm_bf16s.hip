@@ -924,10 +924,10 @@ static int hs_launch_nt(const HsArgs& g, const char* label, hipStream_t st) {
     if (vi < 0 || vi >= kNtCount) { set_error("unknown bf16-storage GEMM variant %d", vi); return VAEK_ERR_INVALID; }
     const HsNtVariant& v = kNt[vi];
     const HsNtKernel fn = EPI == HS_FWD ? v.fwd : v.dx;
-    static thread_local bool attr_set[2][kNtCount] = {};
-    if (!attr_set[EPI][vi]) {
+    static thread_local PerDeviceOnce attr_set[2][kNtCount];
+    if (attr_set[EPI][vi].need()) {
         VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
-        attr_set[EPI][vi] = true;
+        attr_set[EPI][vi].mark();
     }
     unsigned grid = (unsigned)(((g.M + v.bm - 1) / v.bm) * ((g.N + v.bn - 1) / v.bn));
     if (v.persistent) grid = std::min(grid, 256u);         // one resident workgroup per CU walks the tiles
@@ -967,10 +967,10 @@ int launch_hs_dw(const __bf16* x, const __bf16* dy, float* slab0, int64_t slab_s
     if (vi < 0 || vi >= kTnCount) { set_error("unknown bf16-storage dW variant %d", vi); return VAEK_ERR_INVALID; }
     const HsTnVariant& v = kTn[vi];
     g.tiles_m = (n_in + v.bm - 1) / v.bm; g.tiles_n = (n_out + 127) / 128;
-    static thread_local bool attr_set[kTnCount] = {};
-    if (!attr_set[vi]) {
+    static thread_local PerDeviceOnce attr_set[kTnCount];
+    if (attr_set[vi].need()) {
         VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
-        attr_set[vi] = true;
+        attr_set[vi].mark();
     }
     ProfScope ps("gemm_bf16s_dw", st);
     launch_k(ps, v.fn, dim3((unsigned)(g.tiles_m * g.tiles_n * S)), dim3(2 * v.bm), v.lds, st, g);
@@ -1012,8 +1012,8 @@ int launch_hs_conv_dw(const __bf16* x, const __bf16* dy, const __bf16* zeros, fl
     const bool narrow = Cout <= 64;
     const auto fn = narrow ? hs_tn_kernel<64, 2, true, true> : hs_tn_kernel<64, 2, true>;
     const size_t lds = 2 * 2 * 64 * 256;
-    static thread_local bool attr_set[2] = {false, false};
-    if (!attr_set[narrow]) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set[narrow] = true; }
+    static thread_local PerDeviceOnce attr_set[2];
+    if (attr_set[narrow].need()) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set[narrow].mark(); }
     ProfScope ps("conv_wgrad_bf16s", st);
     launch_k(ps, fn, dim3((unsigned)(g.tiles_m * g.tiles_n * S)), dim3(256), lds, st, g);
     VAEK_HIP_CHECK(hipGetLastError());
@@ -1025,8 +1025,8 @@ template <int MODE, int BN, int WM, int WN, int BK, int NS, int BM = 128>
 static int hs_conv_launch(const HsConvArgs& g, hipStream_t st) {
     const auto fn = hs_conv_kernel<MODE, BN, WM, WN, BK, NS, BM>;
     constexpr size_t lds = (size_t)NS * (BM + BN) * 2 * BK;
-    static thread_local bool attr_set = false;
-    if (!attr_set) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+    static thread_local PerDeviceOnce attr_set;
+    if (attr_set.need()) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set.mark(); }
     ProfScope ps(MODE == HC_FWD ? "conv_fwd_bf16s" : "conv_t_fwd_bf16s", st);
     launch_k(ps, fn, dim3((unsigned)(((g.M + BM - 1) / BM) * (g.N / BN)) * (MODE == HC_T ? 4u : 1u)), dim3(64 * WM * WN), lds, st, g);
     VAEK_HIP_CHECK(hipGetLastError());

@@ -599,19 +599,19 @@ int launch_sk_last_bwd(const __bf16* h, const float* dy, const float* w, __bf16*
         // the matrix-core form: rows in blocks of 16 through a ring of four LDS images of h (+ dy)
         ProfScope ps("sk16_last_bwd", st);
         const size_t lds_m = (size_t)4 * (16 * (2 * H + 32) + 1024);
-        static thread_local bool setm = false;
-        if (!setm) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)sk_last_bwd_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); setm = true; }
+        static thread_local PerDeviceOnce setm;
+        if (setm.need()) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)sk_last_bwd_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); setm.mark(); }
         launch_k(ps, sk_last_bwd_mfma_kernel<8>, dim3(nwg), dim3(256), lds_m, st, a);
         VAEK_HIP_CHECK(hipGetLastError());
     } else {
         ProfScope ps("sk16_last_bwd", st);
         if (d <= 8) {
-            static thread_local bool set8 = false;
-            if (!set8) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)sk_last_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set8 = true; }
+            static thread_local PerDeviceOnce set8;
+            if (set8.need()) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)sk_last_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set8.mark(); }
             launch_k(ps, sk_last_bwd_kernel<8>, dim3(nwg), dim3(256), lds, st, a);
         } else {
-            static thread_local bool set16 = false;
-            if (!set16) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)sk_last_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set16 = true; }
+            static thread_local PerDeviceOnce set16;
+            if (set16.need()) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)sk_last_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set16.mark(); }
             launch_k(ps, sk_last_bwd_kernel<16>, dim3(nwg), dim3(256), lds, st, a);
         }
         VAEK_HIP_CHECK(hipGetLastError());
@@ -629,19 +629,19 @@ int launch_sk_first_bwd(const float* x, const __bf16* dy, float* partial, float*
         // the matrix-core form (sk_last_bwd_mfma_kernel's G product with a ones column)
         ProfScope ps("sk16_first_bwd", st);
         const size_t lds_m = (size_t)4 * (16 * (2 * H + 32) + 1024);
-        static thread_local bool setm = false;
-        if (!setm) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)sk_last_bwd_mfma_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); setm = true; }
+        static thread_local PerDeviceOnce setm;
+        if (setm.need()) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)sk_last_bwd_mfma_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); setm.mark(); }
         launch_k(ps, sk_last_bwd_mfma_kernel<8, true>, dim3(nwg), dim3(256), lds_m, st, a);
         VAEK_HIP_CHECK(hipGetLastError());
     } else {
         ProfScope ps("sk16_first_bwd", st);
         if (d <= 8) {
-            static thread_local bool set8 = false;
-            if (!set8) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)sk_first_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set8 = true; }
+            static thread_local PerDeviceOnce set8;
+            if (set8.need()) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)sk_first_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set8.mark(); }
             launch_k(ps, sk_first_bwd_kernel<8>, dim3(nwg), dim3(256), lds, st, a);
         } else {
-            static thread_local bool set16 = false;
-            if (!set16) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)sk_first_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set16 = true; }
+            static thread_local PerDeviceOnce set16;
+            if (set16.need()) { VAEK_HIP_CHECK(hipFuncSetAttribute((const void*)sk_first_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set16.mark(); }
             launch_k(ps, sk_first_bwd_kernel<16>, dim3(nwg), dim3(256), lds, st, a);
         }
         VAEK_HIP_CHECK(hipGetLastError());

@@ -239,6 +239,14 @@ int launch_sum_slabs_inplace(float* slabs, int64_t stride, int S, float* out, in
 #ifdef __HIPCC__
 int launch_cvt_bf16(const float* src, __bf16* dst, int64_t n, __bf16* zero8, hipStream_t st);
 int launch_cvt_bf16_t(const float* src, __bf16* dst, int K, int N, __bf16* zero8, hipStream_t st);
+// "Has this been set up on the CURRENT device?" -- hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device, and a per-thread
+// flag skipped it for the second device a thread drives (launches needing > 64 KB of LDS then fail with an invalid value).
+struct PerDeviceOnce {
+    unsigned long long mask[2] = {0ull, 0ull};          // devices 0 .. 127
+    static int slot() { int dev = 0; return hipGetDevice(&dev) == hipSuccess ? (dev & 127) : 0; }
+    bool need() const { const int d = slot(); return !(mask[d >> 6] >> (d & 63) & 1ull); }
+    void mark() { const int d = slot(); mask[d >> 6] |= 1ull << (d & 63); }
+};
 int launch_hs_conv(int mode, const __bf16* x, const __bf16* wb, const __bf16* zeros, const float* bias, const float* mask, const __bf16* mask16,
                    float* out, __bf16* out16, int batch, int H, int W, int Cin, int Cout, bool relu, hipStream_t st);      // mode 0: forward, 1: transposed
 int launch_hs_conv_dw(const __bf16* x, const __bf16* dy, const __bf16* zeros, float* slab0, int64_t slab_stride, int S, int rows_per_split,
