@@ -2,9 +2,10 @@
 set -e
 cd $(dirname $0)/../vae_training_amd/csrc
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -DVAEK_FUSED_ONLY_M"
-for f in $(ls *.hip | sed "s/\.hip$//"); do /opt/rocm/bin/hipcc $F -c $f.hip -o /tmp/ab_$f.o; done
-/opt/rocm/bin/hipcc $F -DVAEK_ABLATE=${ABL:-1} -c fused_mfma.hip -o /tmp/ab_fused_mfma.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libvaek_ablate.so /tmp/ab_api.o /tmp/ab_gemm_f32.o /tmp/ab_gemm_bf16.o /tmp/ab_elbo.o /tmp/ab_fused_small.o /tmp/ab_fused_mfma.o /tmp/ab_comm.o /tmp/ab_rng.o /tmp/ab_microbench.o
+rm -rf /tmp/vaek_ab && mkdir -p /tmp/vaek_ab          # a private directory: every object of csrc/, the ablated fused_mfma.o compiled last
+for f in $(ls *.hip | sed "s/\.hip$//" | grep -v "^fused_mfma$"); do /opt/rocm/bin/hipcc $F -c $f.hip -o /tmp/vaek_ab/$f.o & done; wait
+/opt/rocm/bin/hipcc $F -DVAEK_ABLATE=${ABL:-1} -c fused_mfma.hip -o /tmp/vaek_ab/fused_mfma.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libvaek_ablate.so /tmp/vaek_ab/*.o
 cd ../..
 python3 - <<'PY'
 import os, sys
