@@ -402,16 +402,18 @@ def test_conv_vae_loss_and_every_gradient_leaf(size, widths, L, B, tdv, monkeypa
         assert np.sqrt(np.mean((got - want) ** 2)) <= 0.3 * (np.sqrt(np.mean(want ** 2)) + 1e-30), name
 
 
-def test_conv_vae_graph_replay_is_the_eager_step():
+@pytest.mark.parametrize("size,widths,L,B", [(16, (8, 16, 16, 32), 6, 16), (32, (32, 64, 128, 256), 8, 32)])
+def test_conv_vae_graph_replay_is_the_eager_step(size, widths, L, B):
     """ConvVAE.capture: the step as a hipGraph (the tunable eps read on the device, no host access) -- replays walk the same
-    trajectory as eager steps, bit for bit."""
+    trajectory as eager steps, bit for bit.  The second case has config 5's widths: the lean model (bf16-only hidden tensors)."""
     from vae_training_amd.conv_vae import ConvVAE
-    cfg = CO.ConvConfig(16, (8, 16, 16, 32), 6, -1.5, True)
-    B, lr = 16, 2e-3
+    cfg = CO.ConvConfig(size, widths, L, -1.5, True)
+    lr = 2e-3
     p, x, z1, z2 = _conv_problem(cfg, B, seed=5)
     runs = []
     for graph in (False, True):
-        net = ConvVAE(B, 16, (8, 16, 16, 32), 6, -1.5, True)
+        net = ConvVAE(B, size, widths, L, -1.5, True)
+        assert net.lean == (widths[0] >= 32)
         params, grads, m, v = net.new_flat(), net.new_flat(), net.new_flat(), net.new_flat()
         for name in net.leaves:
             net.view(params, name).copy_(_dev(p[name]))

@@ -3,7 +3,7 @@
 set -e
 cd $GRAFT_REPO_ROOT/vae_training_amd/csrc
 mkdir -p /tmp/hsab_common
-for f in $(ls *.hip | sed "s/\.hip$//"); do
+for f in $(ls *.hip | sed "s/\.hip$//" | grep -v "^gemm_bf16s$"); do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -c $f.hip -o /tmp/hsab_common/$f.o &
 done; wait
 for ab in "$@"; do
