@@ -493,12 +493,16 @@ struct HsDwArgs {
 // NARROW (N <= 64): the four waves stack along M (32 rows x 64 columns each) instead of 2 x 2 -- no wave multiplies columns past N
 // BM 256 (eight waves, 4 x 2): the M side is TWO 128-feature images side by side -- 1.5 KB of operands per k-row for twice the
 // products of the 128 x 128 tile's 1 KB
-template <int BK, int NS, bool CONV = false, bool NARROW = false, int BM = 128>
-__global__ __launch_bounds__(2 * BM) void hs_tn_kernel(const HsDwArgs g) {
+// LW > 0 (BM 256): LW extra waves do nothing but issue the LDS-DMA pieces (and wait for them); the eight multiplying waves never
+// spend issue slots on loads -- a global_load_lds costs the issuing wave ~100 cycles per KB, and in-order waves add that to their
+// MFMA time (the ablation of the forward GEMM: loads 13 us, MFMAs 11 us, stores 12 us of a 48 us launch, nearly additive).
+template <int BK, int NS, bool CONV = false, bool NARROW = false, int BM = 128, int LW = 0>
+__global__ __launch_bounds__(2 * BM + 64 * LW) void hs_tn_kernel(const HsDwArgs g) {
     constexpr int BN = 128, T_BYTES = BK * 256, NTH = 2 * BM, AT = BM / 128, BUF = (AT + 1) * T_BYTES;
-    constexpr int PPT = BK * 16 / NTH, P = (AT + 1) * PPT;    // staging passes per 128-feature image; loads per k-tile and wave
+    constexpr int STH = LW ? 64 * LW : NTH;                   // threads that stage
+    constexpr int PPT = BK * 16 / STH, P = (AT + 1) * PPT;    // staging passes per 128-feature image; loads per k-tile and (staging) wave
     constexpr int PASSES = AT * PPT;                          // ... of the A side
-    static_assert(BK * 16 % NTH == 0 && (BM == 128 || (!CONV && !NARROW)), "whole staging passes");
+    static_assert(BK * 16 % STH == 0 && (BM == 128 || (!CONV && !NARROW)) && (LW == 0 || BM == 256), "whole staging passes");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned tiles = g.tiles_m * g.tiles_n, nb = gridDim.x;
     unsigned id = blockIdx.x;
@@ -511,13 +515,15 @@ __global__ __launch_bounds__(2 * BM) void hs_tn_kernel(const HsDwArgs g) {
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     constexpr int TI = NARROW ? 1 : 2, WROWS = NARROW ? 32 : 64;      // m-fragments per wave, rows of M per wave
     const int wm = NARROW ? wv : wv >> 1, wn = NARROW ? 0 : wv & 1;
+    const bool stager = LW == 0 || wv >= NTH / 64;                    // does this wave issue loads?
+    const int st = LW ? t - NTH : t, swv = LW ? wv - NTH / 64 : wv;   // its index among the staging threads / waves
 
     // staging: 16 BK chunks per 128-feature image; position p -> k-row p >> 4, chunk slot p & 15; pass i of the A side belongs to
     // image i / PPT
     int a_col[PASSES], b_col[PPT], s_row[PPT];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-        const int p = i * NTH + t, row = p >> 4, ch = (p & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        const int p = i * STH + (st & (STH - 1)), row = p >> 4, ch = (p & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
         s_row[i] = row;
         b_col[i] = min(n0 + ch * 8, g.N - 8);        // a partial last tile re-reads valid columns; those outputs are not stored
 #pragma unroll
@@ -540,8 +546,8 @@ __global__ __launch_bounds__(2 * BM) void hs_tn_kernel(const HsDwArgs g) {
                 const long long krow = min(k0 + s_row[i], g.rows - 1);
 #pragma unroll
                 for (int im = 0; im < AT; ++im)
-                    glds16(g.X + krow * g.ldx + a_col[im * PPT + i], base + im * T_BYTES + (i * NTH + wv * 64) * 16);
-                glds16(g.dY + krow * g.ldy + b_col[i], base + AT * T_BYTES + (i * NTH + wv * 64) * 16);
+                    glds16(g.X + krow * g.ldx + a_col[im * PPT + i], base + im * T_BYTES + (i * STH + swv * 64) * 16);
+                glds16(g.dY + krow * g.ldy + b_col[i], base + AT * T_BYTES + (i * STH + swv * 64) * 16);
             }
             return;
         }
@@ -590,13 +596,27 @@ __global__ __launch_bounds__(2 * BM) void hs_tn_kernel(const HsDwArgs g) {
         return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(smem + addr));
     };
     const int nt = (kend - kbeg + BK - 1) / BK;
+    if (stager) {
 #pragma unroll
-    for (int qq = 0; qq < NS - 1; ++qq) if (qq < nt) stage(kbeg + qq * BK, qq);
+        for (int qq = 0; qq < NS - 1; ++qq) if (qq < nt) stage(kbeg + qq * BK, qq);
+    }
     int slot = 0, fill = NS - 1;
+    if constexpr (LW > 0) {
+        if (stager) {                               // the loading waves' whole life: wait, meet the others, issue the tile NS - 1 ahead
+            for (int kt = 0; kt < nt; ++kt) {
+                wait_tiles<P, NS - 2>(min(NS - 2, nt - 1 - kt));
+                __builtin_amdgcn_s_barrier();
+                if (kt + NS - 1 < nt) stage(kbeg + (kt + NS - 1) * BK, fill);
+                if (kend - (kbeg + kt * BK) < BK) __syncthreads();       // (the others zero the rows past the end: see below)
+                fill = fill + 1 == NS ? 0 : fill + 1;
+            }
+            return;
+        }
+    }
     for (int kt = 0; kt < nt; ++kt) {
-        wait_tiles<P, NS - 2>(min(NS - 2, nt - 1 - kt));
+        if constexpr (LW == 0) wait_tiles<P, NS - 2>(min(NS - 2, nt - 1 - kt));
         __builtin_amdgcn_s_barrier();
-        if (kt + NS - 1 < nt) stage(kbeg + (kt + NS - 1) * BK, fill);
+        if constexpr (LW == 0) { if (kt + NS - 1 < nt) stage(kbeg + (kt + NS - 1) * BK, fill); }
         const int boff = slot * BUF;
         const int valid = kend - (kbeg + kt * BK);
         if (valid < BK) {                           // last k-tile of the batch: rows past the end must contribute zero
@@ -898,7 +918,7 @@ static const HsNtVariant kNt[] = {
 };
 constexpr int kNtCount = sizeof(kNt) / sizeof(kNt[0]);
 typedef void (*HsTnKernel)(const HsDwArgs);
-struct HsTnVariant { HsTnKernel fn; size_t lds; const char* name; int bm; };
+struct HsTnVariant { HsTnKernel fn; size_t lds; const char* name; int bm; int nth = 0; };      // nth: threads per workgroup (0: 2 bm)
 static const HsTnVariant kTn[] = {
     {hs_tn_kernel<64, 2>, 2 * 2 * 64 * 256, "128x128x64 ring2", 128},      // 0: the first version
     {hs_tn_kernel<32, 5>, 5 * 2 * 32 * 256, "128x128x32 ring5", 128},      // 1
@@ -908,6 +928,8 @@ static const HsTnVariant kTn[] = {
     {hs_tn_kernel<64, 2, false, false, 256>, 2 * 3 * 64 * 256, "256x128x64 ring2", 256},      // 5: eight waves, one workgroup per CU
     {hs_tn_kernel<32, 4, false, false, 256>, 4 * 3 * 32 * 256, "256x128x32 ring4", 256},      // 6
     {hs_tn_kernel<64, 3, false, false, 256>, 3 * 3 * 64 * 256, "256x128x64 ring3", 256},      // 7: 144 KB
+    {hs_tn_kernel<64, 3, false, false, 256, 4>, 3 * 3 * 64 * 256, "256x128x64 ring3 + 4 loading waves", 256, 768},      // 8
+    {hs_tn_kernel<64, 3, false, false, 256, 2>, 3 * 3 * 64 * 256, "256x128x64 ring3 + 2 loading waves", 256, 640},      // 9
 };
 constexpr int kTnCount = sizeof(kTn) / sizeof(kTn[0]);
 // -1 = by shape: 256 x 256 tiles where they still give every CU a workgroup (C3 at full size: forward 50 -> 44 us), 128 x 128
@@ -963,7 +985,7 @@ int launch_hs_dw(const __bf16* x, const __bf16* dy, float* slab0, int64_t slab_s
     // 45 us with the LDS-DMA in inline assembly and a ring of three)
     // where they still give most CUs a workgroup, 128 x 128 otherwise; every variant bitwise identical for the same splits
     const bool big = n_in % 256 == 0 && (long long)(n_in / 256) * ((n_out + 127) / 128) * S >= 192;
-    const int vi = g_hs_variant_tn >= 0 ? g_hs_variant_tn : (big ? 7 : 0);      // (7: ring of three 64-row k-tiles -- 45 us where the ring of two takes 52, now that loads and products overlap)
+    const int vi = g_hs_variant_tn >= 0 ? g_hs_variant_tn : (big ? 8 : 0);      // (8: ring of three 64-row k-tiles + four loading waves: 43 us; 7 without them: 45; ring of two: 52)
     if (vi < 0 || vi >= kTnCount) { set_error("unknown bf16-storage dW variant %d", vi); return VAEK_ERR_INVALID; }
     const HsTnVariant& v = kTn[vi];
     g.tiles_m = (n_in + v.bm - 1) / v.bm; g.tiles_n = (n_out + 127) / 128;
@@ -973,7 +995,7 @@ int launch_hs_dw(const __bf16* x, const __bf16* dy, float* slab0, int64_t slab_s
         attr_set[vi].mark();
     }
     ProfScope ps("gemm_bf16s_dw", st);
-    launch_k(ps, v.fn, dim3((unsigned)(g.tiles_m * g.tiles_n * S)), dim3(2 * v.bm), v.lds, st, g);
+    launch_k(ps, v.fn, dim3((unsigned)(g.tiles_m * g.tiles_n * S)), dim3(v.nth ? v.nth : 2 * v.bm), v.lds, st, g);
     VAEK_HIP_CHECK(hipGetLastError());
     return VAEK_OK;
 }
